@@ -1,0 +1,340 @@
+/*
+ * legion_amd.h -- C ABI of liblegion_amd.so, the MI355X-native (HIP, gfx950) implementation
+ * of Legion's GPU-initiated mini-batch pipeline.
+ *
+ * The library is a drop-in for the reference's sampling-server hot path: every entry point
+ * below replaces one interface of liayan/Legion-1 and cites it (paths relative to the
+ * reference tree).  Where the reference already exports a C-linkage symbol
+ * (src/Kernels.cuh:24-93, GPU_Graph_Storage.cuh:38-39, GPU_Node_Storage.cuh:60-61,
+ * CUDA_IPC_Service.h:35) the SAME NAME and argument order are kept; its C++ class pointers
+ * become opaque struct handles, and the C++ virtual methods a caller needs become
+ * `Class_Method(handle, ...)` functions.  No torch / C++ types cross this boundary: plain
+ * pointers, sizes and ints only.  Streams are `void*` (a hipStream_t).
+ *
+ * Error behaviour (reference: cudaCheckError() -> printf + exit(EXIT_FAILURE),
+ * src/Kernels.cuh:14-22): by default a HIP failure prints "Hip failure <file>:<line>: '<msg>'"
+ * and exits, exactly like the reference.  legion_set_error_mode(LEGION_ERR_RETURN) turns
+ * that into a sticky per-thread error readable with legion_last_error() (for embedding /
+ * tests).  Argument errors always take the sticky path.
+ */
+#ifndef LEGION_AMD_H
+#define LEGION_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEGION_MAX_DEVICE 8      /* CUDA_IPC_Service.cu:14 MAX_DEVICE */
+#define LEGION_PIPELINE_DEPTH 2  /* Server.cu:15, CUDA_IPC_Service.cu:15 */
+#define LEGION_MEMORY_USAGE 7    /* CUDA_IPC_Service.cu:16: buffers per (device, pipe) */
+#define LEGION_MAX_HOPS 5        /* counter layout fits int32[16] up to 5 hops */
+
+#define LEGION_TRAINMODE 0       /* Kernels.cu:10-12 */
+#define LEGION_VALIDMODE 1
+#define LEGION_TESTMODE 2
+
+/* ---- opaque handles (reference C++ classes) -------------------------------------------- */
+typedef struct GPUGraphStorage GPUGraphStorage; /* GPU_Graph_Storage.cuh:20-37 */
+typedef struct GPUNodeStorage GPUNodeStorage;   /* GPU_Node_Storage.cuh:24-58 */
+typedef struct GPUCache GPUCache;               /* GPUCache.cuh:64-161 */
+typedef struct GPUMemoryPool GPUMemoryPool;     /* GPUMemoryPool.cuh:7-208 */
+typedef struct IPCEnv IPCEnv;                   /* CUDA_IPC_Service.h:6-33 */
+typedef struct Operator Operator;               /* Operator.h:18-21 */
+typedef struct Runner Runner;                   /* Server.h:157-165 */
+typedef struct Server Server;                   /* Server.h:148-155 */
+
+/* ---- library control --------------------------------------------------------------------- */
+#define LEGION_ERR_EXIT 0   /* reference behaviour */
+#define LEGION_ERR_RETURN 1
+const char* legion_version(void);
+void legion_set_error_mode(int mode);
+const char* legion_last_error(void); /* "" when none; cleared by legion_clear_error */
+void legion_clear_error(void);
+/* Map a logical device id (the reference's dev_id / partition id) onto a physical HIP device.
+ * Default: physical = logical % hipGetDeviceCount.  Lets a clique of Kg logical GPUs be
+ * exercised on fewer physical devices. */
+void legion_set_device_map(int32_t logical_dev, int32_t physical_dev);
+int32_t legion_physical_device(int32_t logical_dev);
+
+/* ---- raw device helpers: src/Kernels.cuh:24-45 (same names) ------------------------------ */
+void* d_alloc_space(int64_t num_bytes);
+void* d_alloc_space_managed(unsigned int num_bytes);
+void d_copy_2_h(void* h_ptr, void* d_ptr, unsigned int num_bytes);
+void d_free_space(void* d_ptr);
+void SetGPUDevice(int32_t shard_id);
+int32_t GetGPUDevice(void);
+void* host_alloc_space(unsigned int num_bytes);   /* pinned + mapped; returns the device alias */
+void* host_alloc_space64(int64_t num_bytes);      /* same without the reference's 4 GiB limit */
+void host_free_space(void* ptr);
+void d_copy_h_2_d(void* d_ptr, const void* h_ptr, int64_t num_bytes);
+void d_copy_d_2_h(void* h_ptr, const void* d_ptr, int64_t num_bytes);
+void d_stream_sync(void* stream);
+void* d_stream_create(void);
+void d_stream_destroy(void* stream);
+
+/* ---- BuildInfo: src/BuildInfo.h:5-70 (the fields the hot path uses; BaM/SSD fields dropped) */
+typedef struct LegionBuildInfo {
+    int32_t partition_count;                         /* == shard count == #logical GPUs */
+    /* per-partition seed sets (host pointers, arrays of partition_count entries) */
+    const int32_t* training_set_num;   const int32_t* const* training_set_ids;   const int32_t* const* training_labels;
+    const int32_t* validation_set_num; const int32_t* const* validation_set_ids; const int32_t* const* validation_labels;
+    const int32_t* testing_set_num;    const int32_t* const* testing_set_ids;    const int32_t* const* testing_labels;
+    /* features */
+    int32_t total_num_nodes;
+    int32_t float_attr_len;
+    float* host_float_attrs;      /* V*F floats.  features_location says where they live */
+    int32_t features_location;    /* LEGION_LOC_* */
+    /* CSR */
+    int64_t* csr_node_index;      /* int64[V+1] */
+    int32_t* csr_dst_node_ids;    /* int32[E]   */
+    int32_t csr_location;         /* LEGION_LOC_* */
+    int64_t total_edge_num;
+    int64_t cache_edge_num;
+    /* train */
+    int32_t epoch;
+    int32_t raw_batch_size;
+} LegionBuildInfo;
+
+/* Where a table handed to Build() lives.  The reference always uses pinned host memory read
+ * by the GPUs through UVA (GPUGraphStore.cu:264-265,315).  On 288 GB parts the whole table
+ * usually fits in HBM, so device-resident tables are first class here. */
+#define LEGION_LOC_HOST_PINNED 0  /* pointer from host_alloc_space*: device-visible host memory */
+#define LEGION_LOC_DEVICE 1       /* pointer is device memory on every logical GPU's physical device */
+#define LEGION_LOC_HOST_PAGEABLE 2 /* plain host pointer: Build() copies it to a pinned mapping */
+
+/* ---- graph storage: GPU_Graph_Storage.cuh:20-39, GPU_Memory_Graph_Storage.cu:45-133 ------- */
+GPUGraphStorage* NewGPUMemoryGraphStorage(void);
+void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info);
+void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity);
+void GPUGraphStorage_Finalize(GPUGraphStorage* g);
+int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g);
+int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g);
+int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g);
+/* fragment of logical GPU part_id as seen from dev_id (NULL when not cached) */
+int64_t* GPUGraphStorage_GetFragmentIndex(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id);
+int32_t* GPUGraphStorage_GetFragmentMatrix(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id);
+void GPUGraphStorage_Delete(GPUGraphStorage* g);
+
+/* ---- node storage: GPU_Node_Storage.cuh:24-61, GPU_Memory_Node_Storage.cu:11-161 ---------- */
+GPUNodeStorage* NewGPUMemoryNodeStorage(void);
+void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info);
+void GPUNodeStorage_Finalize(GPUNodeStorage* n);
+int32_t* GPUNodeStorage_GetTrainingSetIds(const GPUNodeStorage* n, int32_t part_id);
+int32_t* GPUNodeStorage_GetValidationSetIds(const GPUNodeStorage* n, int32_t part_id);
+int32_t* GPUNodeStorage_GetTestingSetIds(const GPUNodeStorage* n, int32_t part_id);
+int32_t* GPUNodeStorage_GetTrainingLabels(const GPUNodeStorage* n, int32_t part_id);
+int32_t* GPUNodeStorage_GetValidationLabels(const GPUNodeStorage* n, int32_t part_id);
+int32_t* GPUNodeStorage_GetTestingLabels(const GPUNodeStorage* n, int32_t part_id);
+int32_t GPUNodeStorage_TrainingSetSize(const GPUNodeStorage* n, int32_t part_id);
+int32_t GPUNodeStorage_ValidationSetSize(const GPUNodeStorage* n, int32_t part_id);
+int32_t GPUNodeStorage_TestingSetSize(const GPUNodeStorage* n, int32_t part_id);
+int32_t GPUNodeStorage_TotalNodeNum(const GPUNodeStorage* n);
+float* GPUNodeStorage_GetAllFloatAttr(const GPUNodeStorage* n);
+int32_t GPUNodeStorage_GetFloatAttrLen(const GPUNodeStorage* n);
+void GPUNodeStorage_Delete(GPUNodeStorage* n);
+
+/* ---- memory pool: GPUMemoryPool.cuh:7-208 ------------------------------------------------- */
+/* The reference pool is a bag of raw pointers set by GPURunner::Initialize (Server.cu:216-247).
+ * Here the pool can allocate its own scratch for a given (V, batch, fan-outs) and records the
+ * static upper bounds that size the launches (no device->host round trips in the hot path). */
+GPUMemoryPool* NewGPUMemoryPool(int32_t pipeline_depth);
+/* Allocates scratch on the current device: dedup/position table u32[V], candidate buffer,
+ * tile counters, cache_search_buffer, agg_src_ids; hops = #entries of fanout. */
+void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, int32_t batch_size,
+                                   const int32_t* fanout, int32_t hops);
+int32_t GPUMemoryPool_NumIds(const GPUMemoryPool* p);   /* B*(1+f0+f0*f1+...), Server.cu:184-196 */
+void GPUMemoryPool_SetSampledIds(GPUMemoryPool* p, int32_t* ptr, int32_t pipe);
+void GPUMemoryPool_SetFloatFeatures(GPUMemoryPool* p, float* ptr, int32_t pipe);
+void GPUMemoryPool_SetLabels(GPUMemoryPool* p, int32_t* ptr, int32_t pipe);
+void GPUMemoryPool_SetAggSrcOf(GPUMemoryPool* p, int32_t* ptr, int32_t pipe);
+void GPUMemoryPool_SetAggDstOf(GPUMemoryPool* p, int32_t* ptr, int32_t pipe);
+void GPUMemoryPool_SetNodeCounter(GPUMemoryPool* p, int32_t* ptr, int32_t pipe);
+void GPUMemoryPool_SetEdgeCounter(GPUMemoryPool* p, int32_t* ptr, int32_t pipe);
+/* rows the feature buffers can hold (0 = unknown/unbounded); the gather never writes past it */
+void GPUMemoryPool_SetFeatureRows(GPUMemoryPool* p, int32_t rows);
+void GPUMemoryPool_SetCurrentPipe(GPUMemoryPool* p, int32_t pipe);
+void GPUMemoryPool_SetCurrentMode(GPUMemoryPool* p, int32_t mode);
+void GPUMemoryPool_SetIter(GPUMemoryPool* p, int32_t iter);
+int32_t GPUMemoryPool_GetCurrentMode(const GPUMemoryPool* p);
+int32_t GPUMemoryPool_GetIter(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetSampledIds(const GPUMemoryPool* p);
+float* GPUMemoryPool_GetFloatFeatures(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetLabels(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetAggSrcOf(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetAggDstOf(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetNodeCounter(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetEdgeCounter(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetAggSrcId(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetCacheSearchBuffer(const GPUMemoryPool* p);
+char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p);
+int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p);
+/* The dedup/position table (replaces accessed_map + position_map): u32[V],
+ * 0xFFFFFFFF = not in the current batch, otherwise the node's index in sampled_ids. */
+uint32_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p);
+void GPUMemoryPool_Finalize(GPUMemoryPool* p);
+void GPUMemoryPool_Delete(GPUMemoryPool* p);
+
+/* ---- cache: GPUCache.cuh:64-161, GPUCache.cu:508-872 -------------------------------------- */
+GPUCache* NewGPUCache(void);
+void GPUCache_Initialize(GPUCache* c, int64_t cache_memory, int32_t int_attr_len, int32_t float_attr_len,
+                         int32_t train_step, int32_t device_count);
+void GPUCache_InitializeCacheController(GPUCache* c, int32_t dev_id, int32_t total_num_nodes);
+void GPUCache_Finalize(GPUCache* c, int32_t dev_id);
+int32_t GPUCache_NodeCapacity(const GPUCache* c, int32_t dev_id);
+int32_t GPUCache_EdgeCapacity(const GPUCache* c, int32_t dev_id);
+void GPUCache_FindFeat(GPUCache* c, int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter,
+                       int32_t op_id, void* stream, int32_t dev_id);
+void GPUCache_FindTopo(GPUCache* c, int32_t* input_ids, char* partition_index, int32_t* partition_offset,
+                       int32_t batch_size, int32_t op_id, void* stream, int32_t dev_id);
+void GPUCache_CacheProfiling(GPUCache* c, int32_t* sampled_ids, int32_t* node_counter, void* stream, int32_t dev_id);
+void GPUCache_CandidateSelection(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph);
+/* counters: the two PCIe read-transaction counts the reference takes from Intel PCM
+ * (Server.cu:100, pcm-pcie.h:176-185).  Pass NULL to use the library's PCM-free estimate
+ * derived from the edge hotness collected during pre-sampling. */
+void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph,
+                        const uint64_t* counters, int32_t train_step);
+/* Skip the cost model and impose capacities (rows per GPU) for every clique. */
+void GPUCache_SetCapacity(GPUCache* c, int32_t node_capacity, int32_t edge_capacity);
+void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph);
+int32_t GPUCache_MaxIdNum(const GPUCache* c, int32_t dev_id);
+float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);
+uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id);
+uint64_t* GPUCache_GetEdgeAccessedMap(const GPUCache* c, int32_t dev_id);
+/* ranked candidate lists of clique Ki (device pointers on the clique's first GPU): QF / QT */
+int32_t* GPUCache_GetQF(const GPUCache* c, int32_t Ki);
+int32_t* GPUCache_GetQT(const GPUCache* c, int32_t Ki);
+int32_t GPUCache_Kg(const GPUCache* c);
+int32_t GPUCache_Kc(const GPUCache* c);
+double GPUCache_Alpha(const GPUCache* c, int32_t Ki);
+void GPUCache_Delete(GPUCache* c);
+
+/* ---- mini-batch operators' launchers: src/Kernels.cuh:47-93 (same names, same order) ------ */
+void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cache, GPUMemoryPool* memorypool,
+                            int32_t batch_size, int32_t counter, int32_t part_id, int32_t dev_id, int32_t mode);
+void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache, GPUMemoryPool* memorypool,
+                         int32_t count, int32_t op_id, int is_presc);
+void get_feature_kernel(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool,
+                        int32_t dev_id, int32_t op_id, int in_memory);
+void make_update_plan(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache, GPUMemoryPool* memorypool,
+                      int32_t dev_id, int32_t mode);
+void update_cache(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool,
+                  int32_t dev_id, int32_t mode);
+/* Gather every level of the batch in one launch (rows [0, nc[5+2H]) ): same bytes as running
+ * get_feature_kernel for op 1,3,..,2H+1; used when the per-level overlap is not wanted. */
+void get_feature_kernel_all(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool,
+                            int32_t dev_id, int in_memory);
+
+/* ---- Operator plugin API: src/Operator.h:4-27 ------------------------------------------- */
+typedef struct OpParams {
+    int device_id;
+    void* stream;       /* hipStream_t */
+    void* event;        /* hipEvent_t  */
+    void* memorypool;
+    void* cache;
+    void* graph;
+    void* noder;
+    void* env;
+    int neighbor_count;
+    int is_presc;       /* bool in the reference */
+    int in_memory;      /* bool in the reference */
+} OpParams;
+Operator* NewBatchGenerator(int op_id);
+Operator* NewRandomSampler(int op_id);
+Operator* NewFeatureExtractor(int op_id);
+Operator* NewCachePlanner(int op_id);
+Operator* NewCacheUpdater(int op_id);
+void Operator_run(Operator* op, OpParams* params);
+void Operator_Delete(Operator* op);
+
+/* ---- IPC service, server half: CUDA_IPC_Service.h:6-35, CUDA_IPC_Service.cu:34-360 -------- */
+IPCEnv* NewIPCEnv(int32_t device_count);
+void IPCEnv_Coordinate(IPCEnv* e, const LegionBuildInfo* info);
+int32_t IPCEnv_GetMaxStep(IPCEnv* e);
+void IPCEnv_InitializeSamplesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_ids, int32_t feature_dim,
+                                    int32_t device_id, int32_t pipeline_depth);
+void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_ids, int32_t feature_dim,
+                                     int32_t device_id, int32_t pipeline_depth);
+int32_t IPCEnv_GetRawBatchsize(IPCEnv* e);
+int32_t IPCEnv_GetLocalBatchId(IPCEnv* e, int32_t global_batch_id);
+int32_t IPCEnv_GetCurrentBatchsize(IPCEnv* e, int32_t dev_id, int32_t current_mode);
+int32_t IPCEnv_GetCurrentMode(IPCEnv* e, int32_t global_batch_id);
+int32_t* IPCEnv_GetIds(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+float* IPCEnv_GetFloatFeatures(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+int32_t* IPCEnv_GetLabels(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+int32_t* IPCEnv_GetAggSrc(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+int32_t* IPCEnv_GetAggDst(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+int32_t* IPCEnv_GetNodeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+int32_t* IPCEnv_GetEdgeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+int IPCEnv_IPCTryWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t timeout_ms); /* 0 = acquired */
+void IPCEnv_Finalize(IPCEnv* e);
+int32_t IPCEnv_GetTrainStep(IPCEnv* e);
+/* extension: number of hops published to the trainer (stored after the reference's struct) */
+void IPCEnv_SetHops(IPCEnv* e, int32_t hops);
+/* Namespace for the POSIX shm / semaphore names ("" = the reference's literal names
+ * "simpleIPCshm", "sem_r_D_P", "sem_w_D_P").  Also read from $LEGION_IPC_NAMESPACE. */
+void legion_ipc_set_namespace(const char* ns);
+
+/* ---- IPC service, trainer half: pytorch_extension/ipc_service.h + ipc_cuda_kernel.cu ------ */
+typedef struct LegionIPCClient LegionIPCClient;
+LegionIPCClient* legion_ipc_client_open(int32_t device_id);  /* GPUIPCEnv::Initialize, ipc_cuda_kernel.cu:38-96 */
+void legion_ipc_client_wait(LegionIPCClient* c);              /* Wait(), :98-101 */
+void legion_ipc_client_post(LegionIPCClient* c);              /* Post(), :103-107 */
+/* buffer index: 0 ids 1 features 2 labels 3 agg_src 4 agg_dst 5 node_counter 6 edge_counter
+ * (CUDA_IPC_Service.cu:169-175,209) of the current pipe */
+void* legion_ipc_client_buffer(LegionIPCClient* c, int32_t which);
+void legion_ipc_client_steps(LegionIPCClient* c, int32_t steps[3]);
+int32_t legion_ipc_client_hops(LegionIPCClient* c);
+/* copies both 16-int counters of the current pipe to the host (ipc_cuda_kernel.cu:195-196) */
+void legion_ipc_client_read_counters(LegionIPCClient* c, int32_t h_node_counter[16], int32_t h_edge_counter[16]);
+void legion_ipc_client_close(LegionIPCClient* c);             /* Finalize(), :141-156 */
+
+/* ---- Runner / Server: Server.h:137-165, Server.cu:43-369 ---------------------------------- */
+typedef struct RunnerParams {
+    int device_id;
+    const int32_t* fanout; int32_t hops;   /* std::vector<int> fanout in the reference */
+    void* cache; void* graph; void* noder; void* env;
+    int global_batch_id;
+    int in_memory;
+} RunnerParams;
+Runner* NewGPURunner(void);
+void Runner_Initialize(Runner* r, RunnerParams* params);
+void Runner_InitializeFeaturesBuffer(Runner* r, RunnerParams* params);
+void Runner_RunPreSc(Runner* r, RunnerParams* params);
+void Runner_RunOnce(Runner* r, RunnerParams* params);
+void Runner_Finalize(Runner* r, RunnerParams* params);
+GPUMemoryPool* Runner_GetMemoryPool(Runner* r);
+void Runner_Delete(Runner* r);
+/* Whole server driven by a meta_config file (legion_server.py:58-59, GPUGraphStore.cu:190-223).
+ * fanout may be NULL (reference default {25,10}, Server.cu:68-69). */
+Server* NewGPUServer(void);
+void Server_SetFanout(Server* s, const int32_t* fanout, int32_t hops);
+void Server_SetMetaConfigPath(Server* s, const char* path);
+void Server_Initialize(Server* s, int global_shard_count);
+void Server_PreSc(Server* s, int cache_agg_mode);
+void Server_Run(Server* s);
+void Server_Finalize(Server* s);
+void Server_Delete(Server* s);
+
+/* ---- synthetic datasets (generator spec: legion-1_amd/synth.py) ----------------------------- */
+void legion_synth_degrees(void* stream, int64_t* deg_out, int32_t v0, int32_t n, const int32_t* ladder_host26);
+void legion_synth_neighbors(void* stream, int32_t* indices_out, int64_t e0, int64_t n, int32_t V, uint32_t M, uint32_t C);
+void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F);
+void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int32_t classes);
+void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, int32_t V, uint32_t M2, uint32_t C2, int32_t stride, int32_t phase);
+/* streaming-copy kernel used by bench.py to report the measured HBM peak */
+void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes);
+
+/* ---- self-description for tests ------------------------------------------------------------ */
+/* RNG probe: k[i] = sample index for (idx[i], deg[i]) computed ON THE GPU with the kernel's
+ * own arithmetic (Kernels.cu:402-405 semantics). */
+void legion_rng_probe(void* stream, const int32_t* idx, const int32_t* deg, int32_t* k_out, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LEGION_AMD_H */

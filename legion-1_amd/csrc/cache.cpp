@@ -1,0 +1,360 @@
+// cache.cpp -- host mirror of GPUCache / PreSCCacheController (GPUCache.cuh:9-161,
+// GPUCache.cu:239-872): hotness profiling, candidate ranking, cost model, unified-cache fill-up
+// and the id -> slot lookups.
+//
+// MI355X-first differences:
+//  * the three BGHT cuckoo tables (GPUCache.cu:315-321) are replaced by direct-mapped tables over
+//    [0, V) -- one 4-byte (1-byte) load per key instead of up to 3 x 128-byte bucket probes; the
+//    key -> value / -1 function is identical.
+//  * max_ids_ is tracked on the device (no blocking 64-byte D2H per batch, GPUCache.cu:291).
+//  * ranks >= V are never dereferenced (the reference reads QF/QT out of bounds when
+//    capacity*Kg > V).
+//  * CostModel: when the budget covers all features and all adjacency the reference degenerates
+//    (trans_* stay 0, GPUCache.cu:744-751); we then cache everything.  The Intel-PCM PCIe counter
+//    input is optional: NULL selects an estimate from the edge hotness (one 64-byte read per
+//    sampled edge of the pre-sampling epoch).
+#include "internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <iostream>
+
+using namespace legion;
+
+#define MIN_INTERVAL 0.01 // GPUCache.cu:30
+#define CLS 64            // GPUCache.cu:31
+
+static int kg_of_mode(int cache_agg_mode)
+{   // GPUCache.cu:593-607
+    switch (cache_agg_mode) { case 0: return 1; case 1: return 2; case 2: return 4; case 3: return 8; default: return 0; }
+}
+
+extern "C" {
+
+GPUCache* NewGPUCache(void) { return new GPUCache(); }
+
+// GPUCache::Initialize, GPUCache.cu:508-535
+void GPUCache_Initialize(GPUCache* c, int64_t cache_memory, int32_t int_attr_len, int32_t float_attr_len,
+                         int32_t train_step, int32_t device_count)
+{
+    if (!c || device_count < 1 || device_count > kMaxParts) { LEGION_ARG_ERROR("GPUCache_Initialize: device_count must be 1..8"); return; }
+    c->device_count = device_count;
+    c->ctl.resize(device_count);
+    for (int i = 0; i < device_count; i++) {
+        c->ctl[i] = new CacheController();
+        c->ctl[i]->train_step = train_step;
+        c->ctl[i]->device_count = device_count;
+    }
+    c->float_feature_cache.assign(device_count, nullptr);
+    c->cache_memory = cache_memory;
+    c->int_attr_len = int_attr_len;
+    c->float_attr_len = float_attr_len;
+    c->train_step = train_step;
+    c->is_presc = true;
+}
+
+// PreSCCacheController::Initialize, GPUCache.cu:248-269
+void GPUCache_InitializeCacheController(GPUCache* c, int32_t dev_id, int32_t total_num_nodes)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count) { LEGION_ARG_ERROR("InitializeCacheController: bad dev_id"); return; }
+    CacheController* k = c->ctl[dev_id];
+    DeviceGuard guard(dev_id);
+    k->device_idx = dev_id;
+    k->total_num_nodes = total_num_nodes;
+    HIP_CHECK(hipMalloc(&k->node_access_time, (size_t)total_num_nodes * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemset(k->node_access_time, 0, (size_t)total_num_nodes * sizeof(unsigned long long)));
+    HIP_CHECK(hipMalloc(&k->edge_access_time, (size_t)total_num_nodes * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemset(k->edge_access_time, 0, (size_t)total_num_nodes * sizeof(unsigned long long)));
+    HIP_CHECK(hipMalloc(&k->d_max_ids, sizeof(int32_t)));
+    HIP_CHECK(hipMemset(k->d_max_ids, 0, sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&k->d_global_count, sizeof(int32_t)));
+    k->iter = 0;
+    k->max_ids = 0;
+    HIP_CHECK(hipDeviceSynchronize());
+}
+
+static void free_controller_maps(CacheController* k)
+{
+    if (k->feat_map) (void)hipFree(k->feat_map);
+    if (k->topo_owner) (void)hipFree(k->topo_owner);
+    if (k->topo_row) (void)hipFree(k->topo_row);
+    k->feat_map = nullptr; k->topo_owner = nullptr; k->topo_row = nullptr;
+}
+
+void GPUCache_Finalize(GPUCache* c, int32_t dev_id)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count) return;
+    CacheController* k = c->ctl[dev_id];
+    DeviceGuard guard(dev_id);
+    free_controller_maps(k);
+    if (k->node_access_time) (void)hipFree(k->node_access_time);
+    if (k->edge_access_time) (void)hipFree(k->edge_access_time);
+    if (k->d_max_ids) (void)hipFree(k->d_max_ids);
+    if (k->d_global_count) (void)hipFree(k->d_global_count);
+    k->node_access_time = k->edge_access_time = nullptr;
+    k->d_max_ids = k->d_global_count = nullptr;
+    if (c->float_feature_cache[dev_id]) { (void)hipFree(c->float_feature_cache[dev_id]); c->float_feature_cache[dev_id] = nullptr; }
+}
+
+int32_t GPUCache_NodeCapacity(const GPUCache* c, int32_t dev_id)
+{   // GPUCache.cu:549-551
+    size_t ki = (size_t)(dev_id / (c->Kg > 0 ? c->Kg : 1));
+    return ki < c->node_capacity.size() ? c->node_capacity[ki] : 0;
+}
+int32_t GPUCache_EdgeCapacity(const GPUCache* c, int32_t dev_id)
+{
+    size_t ki = (size_t)(dev_id / (c->Kg > 0 ? c->Kg : 1));
+    return ki < c->edge_capacity.size() ? c->edge_capacity[ki] : 0;
+}
+
+// FindFeat, GPUCache.cu:387-432 (the 500-batch hit-rate print is metrics only and not restated)
+void GPUCache_FindFeat(GPUCache* c, int32_t* sampled_ids, int32_t* cache_offset, int32_t* node_counter,
+                       int32_t op_id, void* stream, int32_t dev_id)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count) { LEGION_ARG_ERROR("FindFeat: bad dev_id"); return; }
+    launch_find_feat((hipStream_t)stream, sampled_ids, cache_offset, node_counter, op_id, c->ctl[dev_id]->feat_map, 1 << 22);
+}
+
+// FindTopo, GPUCache.cu:434-443
+void GPUCache_FindTopo(GPUCache* c, int32_t* input_ids, char* partition_index, int32_t* partition_offset,
+                       int32_t batch_size, int32_t op_id, void* stream, int32_t dev_id)
+{
+    (void)op_id;
+    if (!c || dev_id < 0 || dev_id >= c->device_count) { LEGION_ARG_ERROR("FindTopo: bad dev_id"); return; }
+    CacheController* k = c->ctl[dev_id];
+    launch_find_topo((hipStream_t)stream, input_ids, (int8_t*)partition_index, partition_offset, batch_size, k->topo_owner, k->topo_row);
+}
+
+// CacheProfiling, GPUCache.cu:275-303 (+ GPUCache::CacheProfiling :851-863)
+void GPUCache_CacheProfiling(GPUCache* c, int32_t* sampled_ids, int32_t* node_counter, void* stream, int32_t dev_id)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count) { LEGION_ARG_ERROR("CacheProfiling: bad dev_id"); return; }
+    CacheController* k = c->ctl[dev_id];
+    if (c->is_presc) {
+        launch_hotness((hipStream_t)stream, sampled_ids, node_counter, 0, k->node_access_time, k->d_max_ids, 1 << 22);
+        if (k->iter == (k->train_step - 1)) k->iter = 0;
+    }
+    k->iter++;
+}
+
+int32_t GPUCache_MaxIdNum(const GPUCache* c, int32_t dev_id)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count) return 0;
+    CacheController* k = c->ctl[dev_id];
+    if (k->d_max_ids) {
+        DeviceGuard guard(dev_id);
+        int32_t v = 0;
+        HIP_CHECK(hipMemcpy(&v, k->d_max_ids, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (v > k->max_ids) k->max_ids = v;
+    }
+    return k->max_ids;
+}
+
+// CandidateSelection, GPUCache.cu:578-659
+void GPUCache_CandidateSelection(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph)
+{
+    (void)graph;
+    if (!c || !noder) { LEGION_ARG_ERROR("CandidateSelection: null argument"); return; }
+    const int Kg = kg_of_mode(cache_agg_mode);
+    if (Kg == 0 || c->device_count % Kg != 0) { LEGION_ARG_ERROR("CandidateSelection: cache_agg_mode does not divide the device count"); return; }
+    const int Kc = c->device_count / Kg;
+    c->Kc = Kc;
+    c->Kg = Kg;
+    std::cout << "xGMI Clique: " << Kc << " GPU Per Clique: " << Kg << std::endl;
+    const int32_t V = noder->total_num_nodes;
+    for (auto p : c->QF) if (p) (void)hipFree(p);
+    for (auto p : c->QT) if (p) (void)hipFree(p);
+    for (auto p : c->AF) if (p) (void)hipFree(p);
+    for (auto p : c->AT) if (p) (void)hipFree(p);
+    c->QF.clear(); c->QT.clear(); c->AF.clear(); c->AT.clear();
+    for (int i = 0; i < Kc; i++) {
+        DeviceGuard guard(i * Kg);
+        for (int pass = 0; pass < 2; pass++) {
+            int32_t* order = nullptr;
+            unsigned long long* agg = nullptr;
+            HIP_CHECK(hipMalloc(&order, (size_t)V * sizeof(int32_t)));
+            HIP_CHECK(hipMalloc(&agg, (size_t)V * sizeof(unsigned long long)));
+            HIP_CHECK(hipMemset(agg, 0, (size_t)V * sizeof(unsigned long long)));
+            for (int j = 0; j < Kg; j++) { // peer reads of the clique members' hotness arrays (:624-627,644-647)
+                CacheController* k = c->ctl[i * Kg + j];
+                launch_aggregate_access(nullptr, agg, pass == 0 ? k->node_access_time : k->edge_access_time, V);
+            }
+            launch_iota(nullptr, order, V);
+            sort_by_hotness_desc(nullptr, agg, order, V);
+            if (pass == 0) { c->QF.push_back(order); c->AF.push_back(agg); }
+            else { c->QT.push_back(order); c->AT.push_back(agg); }
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+    }
+    c->is_presc = false;
+}
+
+void GPUCache_SetCapacity(GPUCache* c, int32_t node_capacity, int32_t edge_capacity)
+{
+    c->capacity_forced = true;
+    c->forced_node_capacity = node_capacity;
+    c->forced_edge_capacity = edge_capacity;
+}
+
+// CostModel, GPUCache.cu:661-767
+void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph,
+                        const uint64_t* counters, int32_t train_step)
+{
+    (void)cache_agg_mode;
+    if (!c || !noder || !graph) { LEGION_ARG_ERROR("CostModel: null argument"); return; }
+    const int32_t V = noder->total_num_nodes;
+    const int32_t F = noder->float_attr_len;
+    const int Kg = c->Kg, Kc = c->Kc;
+    c->node_capacity.clear(); c->edge_capacity.clear(); c->alpha.clear();
+    std::cout << "Start solve cost model" << std::endl;
+    for (int i = 0; i < Kc; i++) {
+        if (c->capacity_forced) {
+            c->node_capacity.push_back(c->forced_node_capacity);
+            c->edge_capacity.push_back(c->forced_edge_capacity);
+            c->alpha.push_back(-1.0);
+            continue;
+        }
+        DeviceGuard guard(i * Kg);
+        std::vector<uint64_t> h_node_prefix(V), h_edge_prefix(V), h_edge_mem_prefix(V);
+        {
+            uint64_t* d_tmp = nullptr;
+            uint64_t* d_mem = nullptr;
+            HIP_CHECK(hipMalloc(&d_tmp, (size_t)V * sizeof(uint64_t)));
+            HIP_CHECK(hipMalloc(&d_mem, (size_t)V * sizeof(uint64_t)));
+            inclusive_scan_u64(nullptr, (const uint64_t*)c->AF[i], d_tmp, V);
+            HIP_CHECK(hipMemcpy(h_node_prefix.data(), d_tmp, (size_t)V * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            inclusive_scan_u64(nullptr, (const uint64_t*)c->AT[i], d_tmp, V);
+            HIP_CHECK(hipMemcpy(h_edge_prefix.data(), d_tmp, (size_t)V * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            launch_edge_mem(nullptr, c->QT[i], d_mem, V, graph->csr_node_index_cpu);
+            inclusive_scan_u64(nullptr, d_mem, d_tmp, V);
+            HIP_CHECK(hipMemcpy(h_edge_mem_prefix.data(), d_tmp, (size_t)V * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipFree(d_tmp));
+            HIP_CHECK(hipFree(d_mem));
+        }
+        const int max_payload_size = CLS;
+        const int64_t total_mem = c->cache_memory * Kg;
+        const uint64_t feat_bytes = (uint64_t)V * F * sizeof(float);
+        // MI355X extension: the budget covers everything -> cache everything (see header comment)
+        if ((uint64_t)total_mem >= feat_bytes + h_edge_mem_prefix[V - 1]) {
+            c->node_capacity.push_back(V / Kg + 1);
+            c->edge_capacity.push_back(V / Kg + 1);
+            c->alpha.push_back((double)h_edge_mem_prefix[V - 1] / (double)total_mem);
+            std::cout << "Budget covers all data: caching everything\n";
+            continue;
+        }
+        int64_t memory_step = (int64_t)((double)(c->cache_memory * Kg) * MIN_INTERVAL);
+        if (memory_step < 1) memory_step = 1;
+        uint64_t total_trans_of_topo;
+        if (counters) total_trans_of_topo = counters[0] + counters[1];
+        else total_trans_of_topo = h_edge_prefix[V - 1]; // PCM-free estimate
+        uint64_t total_trans_of_feat = 0;
+        for (int j = 0; j < Kg; j++)
+            total_trans_of_feat += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, i * Kg + j) * train_step * F * (int64_t)sizeof(float)) / max_payload_size);
+
+        int64_t current_mem = 0;
+        const int64_t steps = (total_mem - 1) / memory_step + 1;
+        int64_t current_steps = 0;
+        int32_t node_num_topo = 0, node_num_feat = 0;
+        std::vector<float> trans_of_topo(steps + 1, 0), trans_of_feat(steps + 1, 0), cap_of_topo(steps + 1, 0),
+            cap_of_feat(steps + 1, 0), trans_of_total(steps + 1, 0);
+        for (; current_mem < total_mem; current_mem += memory_step) {
+            if ((uint64_t)current_mem > feat_bytes) node_num_feat = V;
+            else node_num_feat = (int32_t)((current_steps + 1) * (memory_step / (int64_t)(F * sizeof(float))));
+            if ((uint64_t)current_mem > h_edge_mem_prefix[V - 1]) node_num_topo = V;
+            else node_num_topo = (int32_t)(std::lower_bound(h_edge_mem_prefix.begin(), h_edge_mem_prefix.end(), (uint64_t)current_mem) - h_edge_mem_prefix.begin());
+            if (node_num_topo < V) {
+                uint64_t pref = node_num_topo > 0 ? h_edge_prefix[node_num_topo - 1] : 0; // reference reads [-1] at 0
+                trans_of_topo[current_steps] = (float)(total_trans_of_topo * 1.0 / h_edge_prefix[V - 1] * pref);
+                cap_of_topo[current_steps] = (float)(node_num_topo / Kg);
+            }
+            if (node_num_feat < V) {
+                uint64_t pref = node_num_feat > 0 ? h_node_prefix[node_num_feat - 1] : 0;
+                trans_of_feat[current_steps] = (float)(total_trans_of_feat * 1.0 / h_node_prefix[V - 1] * pref);
+                cap_of_feat[current_steps] = (float)(node_num_feat / Kg);
+            }
+            current_steps++;
+        }
+        for (int64_t sidx = 1; sidx < steps; sidx++) trans_of_total[sidx] = trans_of_topo[sidx] + trans_of_feat[steps - 1 - sidx];
+        const int64_t max_sidx = std::max_element(trans_of_total.begin(), trans_of_total.end()) - trans_of_total.begin();
+        std::cout << "Alpha: " << (max_sidx * MIN_INTERVAL) << " Transactions: " << trans_of_total[max_sidx] << std::endl;
+        c->node_capacity.push_back((int32_t)(cap_of_feat[steps - 1 - max_sidx] + 1));
+        c->edge_capacity.push_back((int32_t)(cap_of_topo[max_sidx] + 1));
+        c->alpha.push_back(max_sidx * MIN_INTERVAL);
+        std::cout << "Feat capacity " << cap_of_feat[steps - 1 - max_sidx] << " topo capacity " << cap_of_topo[max_sidx] << std::endl;
+    }
+}
+
+// FillUp, GPUCache.cu:769-826 (+ InitializeMap :306-323, Insert :325-371, FeatFillUp :200-205)
+void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph)
+{
+    (void)cache_agg_mode;
+    if (!c || !noder || !graph) { LEGION_ARG_ERROR("FillUp: null argument"); return; }
+    if ((int)c->node_capacity.size() != c->Kc) { LEGION_ARG_ERROR("FillUp: run CostModel / SetCapacity first"); return; }
+    const int32_t V = noder->total_num_nodes;
+    const int32_t F = noder->float_attr_len;
+    const int Kg = c->Kg;
+    for (int i = 0; i < c->Kc; i++) {
+        const int32_t ncap = c->node_capacity[i], ecap = c->edge_capacity[i];
+        for (int j = 0; j < Kg; j++) {
+            const int dev = i * Kg + j;
+            DeviceGuard guard(dev);
+            CacheController* k = c->ctl[dev];
+            free_controller_maps(k);
+            k->node_capacity = ncap;
+            k->edge_capacity = ecap;
+            HIP_CHECK(hipMalloc(&k->feat_map, (size_t)V * sizeof(int32_t)));
+            HIP_CHECK(hipMalloc(&k->topo_owner, (size_t)V));
+            HIP_CHECK(hipMalloc(&k->topo_row, (size_t)V * sizeof(int32_t)));
+            launch_build_feat_map(nullptr, k->feat_map, c->QF[i], ncap, Kg, V);
+            launch_build_topo_map(nullptr, k->topo_owner, k->topo_row, c->QT[i], ecap, Kg, i, V);
+            if (c->float_feature_cache[dev]) { (void)hipFree(c->float_feature_cache[dev]); c->float_feature_cache[dev] = nullptr; }
+            if (F > 0 && ncap > 0) {
+                float* cache = nullptr;
+                HIP_CHECK(hipMalloc(&cache, (size_t)ncap * F * sizeof(float)));
+                launch_feat_fill_up(nullptr, ncap, F, cache, noder->float_attrs, c->QF[i], Kg, j, V);
+                c->float_feature_cache[dev] = cache;
+            }
+            HIP_CHECK(hipDeviceSynchronize());
+        }
+    }
+    std::cout << "Finish load feature cache\n";
+    for (int i = 0; i < c->Kc; i++) GPUGraphStorage_GraphCache(graph, c->QT[i], i, Kg, c->edge_capacity[i]);
+    std::cout << "Finish load topology cache\n";
+}
+
+float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id)
+{
+    return (dev_id >= 0 && dev_id < c->device_count) ? c->float_feature_cache[dev_id] : nullptr;
+}
+uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id)
+{
+    return (dev_id >= 0 && dev_id < c->device_count) ? (uint64_t*)c->ctl[dev_id]->node_access_time : nullptr;
+}
+uint64_t* GPUCache_GetEdgeAccessedMap(const GPUCache* c, int32_t dev_id)
+{
+    return (dev_id >= 0 && dev_id < c->device_count) ? (uint64_t*)c->ctl[dev_id]->edge_access_time : nullptr;
+}
+int32_t* GPUCache_GetQF(const GPUCache* c, int32_t Ki) { return (Ki >= 0 && Ki < (int)c->QF.size()) ? c->QF[Ki] : nullptr; }
+int32_t* GPUCache_GetQT(const GPUCache* c, int32_t Ki) { return (Ki >= 0 && Ki < (int)c->QT.size()) ? c->QT[Ki] : nullptr; }
+int32_t GPUCache_Kg(const GPUCache* c) { return c->Kg; }
+int32_t GPUCache_Kc(const GPUCache* c) { return c->Kc; }
+double GPUCache_Alpha(const GPUCache* c, int32_t Ki) { return (Ki >= 0 && Ki < (int)c->alpha.size()) ? c->alpha[Ki] : -1.0; }
+
+void GPUCache_Delete(GPUCache* c)
+{
+    if (!c) return;
+    for (int i = 0; i < c->device_count; i++) {
+        GPUCache_Finalize(c, i);
+        delete c->ctl[i];
+    }
+    for (size_t i = 0; i < c->QF.size(); i++) {
+        DeviceGuard guard((int)i * c->Kg);
+        if (c->QF[i]) (void)hipFree(c->QF[i]);
+        if (c->QT[i]) (void)hipFree(c->QT[i]);
+        if (c->AF[i]) (void)hipFree(c->AF[i]);
+        if (c->AT[i]) (void)hipFree(c->AT[i]);
+    }
+    delete c;
+}
+
+} // extern "C"

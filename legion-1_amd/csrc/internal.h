@@ -1,0 +1,216 @@
+// internal.h -- shared declarations of liblegion_amd (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/legion_amd.h"
+
+namespace legion {
+
+// ---- error handling (reference: cudaCheckError(), Kernels.cuh:14-22) -------------------------
+void report_error(const char* file, int line, const char* msg, bool hip_failure);
+bool error_pending();
+inline void check(hipError_t e, const char* file, int line)
+{
+    if (e != hipSuccess) report_error(file, line, hipGetErrorString(e), true);
+}
+#define HIP_CHECK(expr) ::legion::check((expr), __FILE__, __LINE__)
+#define HIP_CHECK_LAST() ::legion::check(hipGetLastError(), __FILE__, __LINE__)
+#define LEGION_ARG_ERROR(msg) ::legion::report_error(__FILE__, __LINE__, (msg), false)
+
+int physical_device(int logical);
+// RAII: switch to the physical device of a logical id, restore on scope exit
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int logical);
+    ~DeviceGuard();
+};
+
+// ---- constants --------------------------------------------------------------------------------
+constexpr uint32_t kUnseen = 0xFFFFFFFFu;      // position-table value: node not in the batch
+constexpr uint32_t kProvisional = 0x80000000u; // | slot idx : claimed in the running hop
+constexpr int kTile = 1024;                    // sampler slots per workgroup tile
+constexpr int kBlock = 256;                    // threads per workgroup
+constexpr int kMaxParts = LEGION_MAX_DEVICE;
+
+// unsigned division by a runtime constant (host precomputed): q = (n * m) >> 32 >> s, n < 2^31
+struct FastDiv {
+    uint32_t d = 1, m = 0, s = 0;
+    FastDiv() = default;
+    explicit FastDiv(uint32_t div);
+};
+
+// ---- kernel launch API (kernels.hip) -------------------------------------------------------------
+struct CsrTables {                 // GPU_Memory_Graph_Storage.cu:45-133: P+1 slots, [P] = whole CSR
+    const int64_t* indptr[kMaxParts + 1];
+    const int32_t* indices[kMaxParts + 1];
+    int32_t partition_count;
+    const int8_t* topo_owner;      // int8[V]  owner logical GPU or -1 (edge_index_map), may be null
+    const int32_t* topo_row;       // int32[V] row in the owner's fragment (edge_offset_map)
+};
+
+struct HopState {                  // written by the scan kernel, read by the write/resolve kernels
+    int32_t edge_base, node_base, n_edges, n_nodes, in_off, n_in, slots, pad;
+};
+
+struct SamplerBuffers {
+    int32_t* sampled_ids;   // IPC buffer 0
+    int32_t* agg_src_ids;   // per-edge neighbour id == next hop's input list
+    int32_t* agg_src_off;   // IPC buffer 3
+    int32_t* agg_dst_off;   // IPC buffer 4
+    int32_t* nc;            // IPC buffer 5
+    int32_t* ec;            // IPC buffer 6
+    uint32_t* pos_map;      // u32[V]
+    int32_t* cand;          // i32[max slots of a hop]
+    int32_t* tile_edge;     // i32[max tiles]
+    int32_t* tile_node;     // i32[max tiles]
+    HopState* hop_state;
+    unsigned long long* edge_access_time; // pre-sampling only (may be null)
+};
+
+void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size, int32_t counter,
+                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, uint32_t* pos_map,
+                 int32_t* nc, int32_t* ec);
+void launch_reset_pos_map(hipStream_t s, uint32_t* pos_map, const int32_t* ids, const int32_t* nc, int32_t hops,
+                          int32_t bound);
+void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers& b, int32_t count, int32_t op_id,
+                       int32_t hops, int32_t slots_bound, bool is_presc);
+void launch_find_feat(hipStream_t s, const int32_t* sampled_ids, int32_t* cache_offset, const int32_t* nc,
+                      int32_t op_id, const int32_t* feat_map, int32_t bound);
+void launch_find_topo(hipStream_t s, const int32_t* input_ids, int8_t* part_index, int32_t* part_offset,
+                      int32_t batch_size, const int8_t* topo_owner, const int32_t* topo_row);
+struct GatherArgs {
+    const float* table;                       // V x F rows: the "cpu_float_attrs" of the reference
+    const float* cache[kMaxParts];            // clique caches (Global_Float_Feature_Cache)
+    const int32_t* feat_map;                  // int32[V] global slot or -1; null = no cache
+    int32_t cache_capacity;                   // rows per GPU
+    int32_t F;
+    int32_t total_num_nodes;
+    const int32_t* sampled_ids;
+    const int32_t* nc;
+    float* dst;
+    int32_t off_idx, size_idx;                // nc[] indices of (offset, size); off_idx < 0 => offset 0
+    int32_t dst_rows;                         // capacity of dst in rows (<= 0: unbounded)
+};
+void launch_gather(hipStream_t s, const GatherArgs& a, int32_t rows_bound);
+void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_t hops, unsigned long long* access,
+                    int32_t* max_ids, int32_t bound);
+void launch_rng_probe(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* k, int32_t n);
+// cache construction helpers
+void launch_aggregate_access(hipStream_t s, unsigned long long* agg, const unsigned long long* add, int32_t n);
+void launch_iota(hipStream_t s, int32_t* out, int32_t n);
+void launch_build_feat_map(hipStream_t s, int32_t* feat_map, const int32_t* QF, int32_t capacity, int32_t Kg, int32_t V);
+void launch_build_topo_map(hipStream_t s, int8_t* owner, int32_t* row, const int32_t* QT, int32_t capacity, int32_t Kg,
+                           int32_t Ki, int32_t V);
+void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
+void launch_fill_i8(hipStream_t s, int8_t* p, int8_t v, int64_t n);
+void launch_feat_fill_up(hipStream_t s, int32_t capacity, int32_t F, float* cache, const float* table, const int32_t* QF,
+                         int32_t Kg, int32_t Ki, int32_t V);
+void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
+                           const int64_t* indptr, int64_t* count_out);
+void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
+                         const int64_t* indptr, const int32_t* indices, const int64_t* frag_indptr,
+                         int32_t* frag_indices);
+void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr);
+void sort_by_hotness_desc(hipStream_t s, unsigned long long* keys, int32_t* ids, int32_t n);
+void inclusive_scan_u64(hipStream_t s, const uint64_t* in, uint64_t* out, int32_t n);
+void inclusive_scan_i64(hipStream_t s, const int64_t* in, int64_t* out, int32_t n);
+
+} // namespace legion
+
+// ---- the opaque handle types (host mirrors of the reference classes) ------------------------------
+struct GPUMemoryPool {
+    int32_t pipeline_depth = LEGION_PIPELINE_DEPTH;
+    int32_t current_pipe = 0, iter = 0, mode = 0, op_id = 0;
+    int32_t device_id = -1;           // logical GPU this pool serves (set by batch_generator_kernel)
+    // scratch owned by the pool when AllocateScratch() was used
+    bool owns_scratch = false;
+    int32_t V = 0, batch_size = 0, hops = 0, num_ids = 0;
+    int32_t fanout[LEGION_MAX_HOPS] = {0};
+    int32_t max_slots = 0, max_tiles = 0;
+    int32_t feature_rows = 0;         // capacity of the feature buffers in rows (0 = unbounded)
+    uint32_t* pos_map = nullptr;
+    int32_t* cand = nullptr;
+    int32_t* tile_edge = nullptr;
+    int32_t* tile_node = nullptr;
+    legion::HopState* hop_state = nullptr;
+    int32_t* cache_search_buffer = nullptr;
+    int32_t* agg_src_ids = nullptr;
+    int8_t* tmp_part_ind = nullptr;
+    int32_t* tmp_part_off = nullptr;
+    // per pipe (IPC buffers)
+    std::vector<float*> float_features;
+    std::vector<int32_t*> labels, node_counter, edge_counter, sampled_ids, agg_src_off, agg_dst_off;
+    // host-side launch bounds (no device round trips)
+    int32_t bound_n = 0;        // upper bound of the next hop's input count
+    int32_t bound_nodes = 0;    // upper bound of nodes discovered so far
+    int32_t level_bound[LEGION_MAX_HOPS + 1] = {0};
+    // residue of the previous batch that still has to be wiped from pos_map
+    const int32_t* dirty_ids = nullptr;
+    const int32_t* dirty_nc = nullptr;
+    int32_t dirty_bound = 0;
+    explicit GPUMemoryPool(int32_t depth);
+};
+
+struct GPUGraphStorage {
+    int32_t partition_count = 0;
+    int32_t node_num = 0;
+    int64_t edge_num = 0, cache_edge_num = 0;
+    int64_t* csr_node_index_cpu = nullptr;   // device-visible pointer of the whole CSR (slot [P])
+    int32_t* csr_dst_node_ids_cpu = nullptr;
+    int32_t csr_location = LEGION_LOC_HOST_PINNED;
+    bool owns_csr = false;
+    // fragments per logical GPU (device memory on that GPU's physical device)
+    std::vector<int64_t*> frag_indptr;
+    std::vector<int32_t*> frag_indices;
+    std::vector<int32_t> frag_rows;
+    // which fragments logical GPU d may read (its clique): table[d][p]
+    std::vector<std::vector<int64_t*>> view_indptr;
+    std::vector<std::vector<int32_t*>> view_indices;
+};
+
+struct GPUNodeStorage {
+    int32_t partition_count = 0, total_num_nodes = 0, float_attr_len = 0;
+    float* float_attrs = nullptr;     // device-visible V x F table
+    int32_t features_location = LEGION_LOC_HOST_PINNED;
+    bool owns_features = false;
+    std::vector<int32_t> training_set_num, validation_set_num, testing_set_num;
+    std::vector<int32_t*> training_set_ids, validation_set_ids, testing_set_ids;
+    std::vector<int32_t*> training_labels, validation_labels, testing_labels;
+};
+
+struct CacheController {              // PreSCCacheController, GPUCache.cu:239-500
+    int32_t device_idx = 0, device_count = 1, total_num_nodes = 0, train_step = 0;
+    unsigned long long* node_access_time = nullptr;
+    unsigned long long* edge_access_time = nullptr;
+    int32_t iter = 0, max_ids = 0;
+    int32_t* d_max_ids = nullptr;     // device-side running max of nc[total]
+    int32_t node_capacity = 0, edge_capacity = 0;
+    // direct-mapped replacements of the three BGHT maps (GPUCache.cu:315-321)
+    int32_t* feat_map = nullptr;      // node_map_:       id -> global cache slot | -1
+    int8_t* topo_owner = nullptr;     // edge_index_map_: id -> owner logical GPU | -1
+    int32_t* topo_row = nullptr;      // edge_offset_map_: id -> row in owner's fragment | -1
+    int32_t* d_global_count = nullptr;
+    int32_t find_iter = 0;
+    int64_t h_cache_hit = 0;
+};
+
+struct GPUCache {
+    int32_t device_count = 0;
+    std::vector<CacheController*> ctl;
+    std::vector<int32_t*> QF, QT;                    // per clique, on the clique's first GPU
+    std::vector<unsigned long long*> AF, AT;
+    int Kc = 1, Kg = 1;
+    std::vector<int32_t> node_capacity, edge_capacity;   // per clique
+    std::vector<double> alpha;
+    int64_t cache_memory = 0;
+    int32_t int_attr_len = 0, float_attr_len = 0, train_step = 0;
+    std::vector<float*> float_feature_cache;         // per logical GPU
+    bool is_presc = true;
+    bool capacity_forced = false;
+    int32_t forced_node_capacity = 0, forced_edge_capacity = 0;
+};

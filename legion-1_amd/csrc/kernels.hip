@@ -1,0 +1,876 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the mini-batch hot path.
+//
+// Reference semantics restated (liayan/Legion-1, src/):
+//   S1 batch_generator                Kernels.cu:68-96      -> k_seed
+//   S2 update_counter                 Kernels.cu:112-150    -> folded into k_seed / k_scan_tiles
+//   S3 kernel_random_sampler_2        Kernels.cu:342-448    -> k_sample + k_mark + k_scan_tiles + k_write
+//   S3' kernel_pre_sampler_optimized  Kernels.cu:468-564    -> k_sample<PRESC>
+//   S4 construct_graph                Kernels.cu:450-463    -> k_write (dst side) + k_resolve (src side)
+//   S5 zero_copy_with_aggregated_cache Kernels.cu:662-702   -> k_gather
+//   S6 FindFeat/FindTopo (BGHT find)  GPUCache.cu:387-461   -> direct-mapped int32/int8[V] tables
+//   S7 ClearPosMap / HotnessMeasure   Kernels.cu:750-756, GPUCache.cu:227-235
+//
+// Design (DESIGN.md has the long form):
+//  * The reference's output ORDER depends on LDS/global atomicAdd races.  We produce the
+//    canonical schedule (serial, slot-index ascending) deterministically: a hop is
+//      k_sample : every slot draws its neighbour (same Thrust minstd arithmetic), parks it in
+//                 cand[idx] and claims the node with atomicMin(pos_map[dst], PROVISIONAL|idx),
+//                 so the LOWEST slot that touches a new node wins -- exactly the serial order;
+//      k_mark   : the winner of each new node is flagged, per-tile edge/node counts are known;
+//      k_scan   : one workgroup prefix-sums the tile counts and applies update_counter (S2);
+//      k_write  : ordered compaction (wave ballot + popcount prefix, one LDS exchange per tile)
+//                 appends edges / new nodes at their canonical positions;
+//      k_resolve: src-side COO offsets through the now final position table.
+//  * One u32[V] table replaces accessed_map (bitmap) + position_map: 0xFFFFFFFF = unseen,
+//    0x80000000|idx = claimed this hop, else final index in sampled_ids.  No V/8-byte memset per
+//    batch; the table is wiped by scattering over the batch's own ids (ClearPosMap's job).
+//  * Row descriptors (start, degree) of a tile are fetched once per source row and staged in
+//    LDS -- the reference re-reads both int64 indptr words in each of the `count` lanes.
+//  * RNG: x = 48271^(idx+1) mod (2^31-1).  Per thread: one table lookup and one Mersenne
+//    mul-mod per tile instead of Thrust's discard() chain of 2*log2(idx) 64-bit `%`.
+//    The final fp64 divide/multiply/truncate is kept verbatim -- it is what makes k bit exact.
+//  * All loop bounds come from device counters; launches are sized by static upper bounds, so
+//    there is not a single device->host copy in the batch (the reference does 7).
+#include "internal.h"
+#include <hipcub/hipcub.hpp>
+#include <mutex>
+
+namespace legion {
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kP31 = 2147483647u; // minstd modulus 2^31 - 1
+constexpr uint32_t kA = 48271u;        // minstd multiplier
+
+__host__ __device__ inline uint32_t mulmod31(uint32_t a, uint32_t b)
+{
+    uint64_t p = (uint64_t)a * (uint64_t)b;
+    uint32_t r = (uint32_t)(p & kP31) + (uint32_t)(p >> 31); // < 2^32
+    r = (r & kP31) + (r >> 31);
+    return r >= kP31 ? r - kP31 : r;
+}
+
+__host__ __device__ inline uint32_t powmod31(uint32_t base, uint64_t e)
+{
+    uint32_t r = 1;
+    while (e) {
+        if (e & 1) r = mulmod31(r, base);
+        base = mulmod31(base, base);
+        e >>= 1;
+    }
+    return r;
+}
+
+// thrust::uniform_int_distribution<int>(0, deg-1) fed with x = minstd value (Kernels.cu:402-405;
+// thrust/random/detail/uniform_int_distribution.inl:73-89, uniform_real_distribution.inl:71-79)
+__device__ inline int32_t sample_index(uint32_t x, int32_t deg)
+{
+    double result = (double)(uint32_t)(x - 1u);
+    result /= 2147483646.0;                  // 1.0 + double(max - min), max-min = 2147483645
+    return (int32_t)(result * (double)deg + 0.0);
+}
+
+__device__ inline uint32_t fdiv(uint32_t n, const FastDiv& d)
+{
+    return d.d == 1 ? n : (uint32_t)(((uint64_t)n * d.m) >> d.s);
+}
+
+__device__ inline int lane_id() { return threadIdx.x & 63; }
+__device__ inline int wave_id() { return threadIdx.x >> 6; }
+
+// level (offset,size) slots of the generalised counter layout
+__device__ inline int32_t total_nodes(const int32_t* nc, int32_t hops) { return nc[5 + 2 * hops]; }
+
+// ------------------------------------------------------------------------------------------------
+// S1 + S2(op 0): seed batch
+// ------------------------------------------------------------------------------------------------
+// Kernel's `batch_size` is the launcher's clamped `size` -- the reference passes `size`
+// (Kernels.cu:227), so the read offset is size*counter (restated, not "fixed").
+__global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids, int32_t* __restrict__ labels,
+                                                 int32_t size, int32_t counter, const int32_t* __restrict__ all_ids,
+                                                 const int32_t* __restrict__ all_labels, int32_t total_cap,
+                                                 uint32_t* __restrict__ pos_map, int32_t* __restrict__ nc,
+                                                 int32_t* __restrict__ ec)
+{
+    int32_t idx = threadIdx.x + blockDim.x * blockIdx.x;
+    if (idx < size) {
+        int32_t g = size * counter + idx;
+        if (g >= total_cap) {
+            batch_ids[idx] = -1;
+            labels[idx] = -1;
+        } else {
+            int32_t src_id = all_ids[g % total_cap];
+            batch_ids[idx] = src_id;
+            pos_map[src_id] = (uint32_t)idx;
+            labels[idx] = all_labels[g % total_cap];
+        }
+    }
+    if (idx < 16) { // cudaMemsetAsync(counters) + update_counter(op 0), Kernels.cu:220-221,118-127
+        int32_t nv = 0;
+        if (idx == 0 || idx == 2 || idx == 4) nv = size;
+        nc[idx] = nv;
+        ec[idx] = 0;
+    }
+}
+
+// S7: ClearPosMap (Kernels.cu:750-756) -- wipe the table over the batch's own ids
+__global__ __launch_bounds__(kBlock) void k_reset_pos_map(uint32_t* __restrict__ pos_map,
+                                                          const int32_t* __restrict__ ids,
+                                                          const int32_t* __restrict__ nc, int32_t hops)
+{
+    // nc[0] is the append cursor: == nc[5+2H] (nc[9] at H=2) once the last hop ran, and still
+    // right when a batch was abandoned after fewer hops.
+    const int32_t n = nc[0];
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int32_t id = ids[i];
+        if (id >= 0) pos_map[id] = kUnseen;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3: sampler, pass 1 -- draw + claim
+// ------------------------------------------------------------------------------------------------
+struct SampleArgs {
+    CsrTables csr;
+    const int32_t* sampled_ids;
+    const int32_t* agg_src_ids;
+    const int32_t* nc;
+    const int32_t* ec;
+    uint32_t* pos_map;
+    int32_t* cand;
+    int32_t* tile_edge;
+    unsigned long long* edge_access_time;
+    const uint32_t* pow_tab;   // pow_tab[m] = 48271^(m+1), m < kTile
+    uint32_t a_tile;           // 48271^kTile
+    uint32_t a_step;           // 48271^(kTile * gridDim.x)
+    FastDiv fdiv;              // / count
+    int32_t count;
+    int32_t op_id;
+};
+
+template <bool PRESC, bool PARTITIONED>
+__global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
+{
+    __shared__ const int32_t* s_row[kTile + 2]; // pointer to the first neighbour of the staged row
+    __shared__ int32_t s_deg[kTile + 2];
+    __shared__ int32_t s_src[kTile + 2];
+    __shared__ int32_t s_cnt[kBlock / 64];
+
+    const int32_t N = a.nc[2];
+    const int32_t f = a.count;
+    const int32_t total = N * f; // int32 like the reference (Kernels.cu:375)
+    const int32_t* __restrict__ input = (a.op_id == 2) ? a.sampled_ids : a.agg_src_ids + a.ec[2];
+    const int32_t n_tiles = (total + kTile - 1) / kTile;
+    const int P = a.csr.partition_count;
+    const int tid = threadIdx.x;
+
+    if ((int32_t)blockIdx.x >= n_tiles) return;
+
+    // per-thread RNG state: x[s] = 48271^(tile*kTile + tid + 256*s + 1)
+    uint32_t x[kTile / kBlock];
+    {
+        uint32_t base = powmod31(a.a_tile, (uint64_t)blockIdx.x); // uniform per workgroup
+#pragma unroll
+        for (int s = 0; s < kTile / kBlock; s++) x[s] = mulmod31(base, a.pow_tab[tid + kBlock * s]);
+    }
+
+    for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int32_t tile_start = tile * kTile;
+        const int32_t tile_end = min(tile_start + kTile, total);
+        const int32_t i0 = (int32_t)fdiv((uint32_t)tile_start, a.fdiv);
+        const int32_t i_last = (int32_t)fdiv((uint32_t)(tile_end - 1), a.fdiv);
+        const int32_t nrows = i_last - i0 + 1;
+
+        // stage the row descriptors of this tile in LDS (one global fetch per source row)
+        for (int32_t r = tid; r < nrows; r += kBlock) {
+            const int32_t src = input[i0 + r];
+            const int32_t* rowp = nullptr;
+            int32_t deg = -1;
+            if (src >= 0) {
+                int32_t row = src;
+                const int64_t* ip = a.csr.indptr[P];
+                const int32_t* ix = a.csr.indices[P];
+                if (PARTITIONED && !PRESC) {
+                    const int8_t owner = a.csr.topo_owner[src]; // FindTopo fused (GPUCache.cu:434-443)
+                    if (owner >= 0) {
+                        row = a.csr.topo_row[src];
+                        for (int p = 0; p < P; p++) // uniform index into the kernel-argument tables
+                            if (owner == p) { ip = a.csr.indptr[p]; ix = a.csr.indices[p]; }
+                    }
+                }
+                const int64_t start = ip[row];
+                deg = (int32_t)(ip[row + 1] - start); // int32 truncation as in Kernels.cu:393,396
+                rowp = ix + start;
+            }
+            s_row[r] = rowp;
+            s_deg[r] = deg;
+            s_src[r] = src;
+        }
+        __syncthreads();
+
+        int32_t cnt = 0;
+#pragma unroll
+        for (int s = 0; s < kTile / kBlock; s++) {
+            const int32_t idx = tile_start + tid + kBlock * s;
+            int32_t dst = -1;
+            if (idx < tile_end) {
+                const uint32_t i = fdiv((uint32_t)idx, a.fdiv);
+                const int32_t j = idx - (int32_t)i * f;
+                const int32_t r = (int32_t)i - i0;
+                const int32_t deg = s_deg[r];
+                if (j < deg) { // deg == -1 for padded (-1) sources; Kernels.cu:385,399
+                    const int32_t k = sample_index(x[s], deg);
+                    dst = s_row[r][k];
+                    if (dst >= 0) {
+                        if (PRESC) atomicAdd(a.edge_access_time + s_src[r], 1ull); // Kernels.cu:525
+                        // claim: lowest idx wins.  A stale (larger) read only costs a redundant atomic.
+                        const uint32_t mine = kProvisional | (uint32_t)idx;
+                        const uint32_t cur = a.pos_map[dst];
+                        if (cur > mine) atomicMin(a.pos_map + dst, mine);
+                        cnt++;
+                    } else {
+                        dst = -1;
+                    }
+                }
+                a.cand[idx] = dst;
+            }
+        }
+        // tile edge count
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+        if (lane_id() == 0) s_cnt[wave_id()] = cnt;
+        __syncthreads();
+        if (tid == 0) {
+            int32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) t += s_cnt[w];
+            a.tile_edge[tile] = t;
+        }
+#pragma unroll
+        for (int s = 0; s < kTile / kBlock; s++) x[s] = mulmod31(x[s], a.a_step);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3 pass 2 -- flag the winners (bit 31 of cand), count new nodes per tile
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, int32_t count,
+                                                 const uint32_t* __restrict__ pos_map, int32_t* __restrict__ cand,
+                                                 int32_t* __restrict__ tile_node)
+{
+    __shared__ int32_t s_cnt[kBlock / 64];
+    const int32_t total = nc[2] * count;
+    const int32_t n_tiles = (total + kTile - 1) / kTile;
+    for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int32_t cnt = 0;
+        int32_t c[kTile / kBlock];
+        uint32_t v[kTile / kBlock];
+#pragma unroll
+        for (int s = 0; s < kTile / kBlock; s++) {
+            const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
+            c[s] = (idx < total) ? cand[idx] : -1;
+        }
+#pragma unroll
+        for (int s = 0; s < kTile / kBlock; s++) v[s] = (c[s] >= 0) ? pos_map[c[s]] : 0u;
+#pragma unroll
+        for (int s = 0; s < kTile / kBlock; s++) {
+            const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
+            if (c[s] >= 0 && v[s] == (kProvisional | (uint32_t)idx)) {
+                cand[idx] = (int32_t)((uint32_t)c[s] | 0x80000000u);
+                cnt++;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+        if (lane_id() == 0) s_cnt[wave_id()] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t t = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) t += s_cnt[w];
+            tile_node[tile] = t;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3 pass 3 -- exclusive scan of the tile counts (one workgroup) + update_counter (S2)
+// ------------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 1024;
+__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(int32_t* __restrict__ nc, int32_t* __restrict__ ec,
+                                                          int32_t count, int32_t op_id, int32_t hops,
+                                                          int32_t* __restrict__ tile_edge,
+                                                          int32_t* __restrict__ tile_node,
+                                                          HopState* __restrict__ hs)
+{
+    __shared__ int32_t s_e[kScanBlock];
+    __shared__ int32_t s_n[kScanBlock];
+    const int32_t N = nc[2];
+    const int32_t total = N * count;
+    const int32_t n_tiles = (total + kTile - 1) / kTile;
+    const int tid = threadIdx.x;
+    const int32_t per = (n_tiles + kScanBlock - 1) / kScanBlock;
+    const int32_t lo = min(tid * per, n_tiles), hi = min(lo + per, n_tiles);
+    int32_t se = 0, sn = 0;
+    for (int32_t t = lo; t < hi; t++) { se += tile_edge[t]; sn += tile_node[t]; }
+    s_e[tid] = se; s_n[tid] = sn;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int o = 1; o < kScanBlock; o <<= 1) {
+        int32_t ae = 0, an = 0;
+        if (tid >= o) { ae = s_e[tid - o]; an = s_n[tid - o]; }
+        __syncthreads();
+        s_e[tid] += ae; s_n[tid] += an;
+        __syncthreads();
+    }
+    int32_t be = s_e[tid] - se, bn = s_n[tid] - sn; // exclusive base of this thread's chunk
+    for (int32_t t = lo; t < hi; t++) {
+        int32_t e = tile_edge[t], n = tile_node[t];
+        tile_edge[t] = be; tile_node[t] = bn;
+        be += e; bn += n;
+    }
+    if (tid == kScanBlock - 1) {
+        const int32_t n_edges = s_e[tid], n_nodes = s_n[tid];
+        HopState h;
+        h.edge_base = ec[0]; h.node_base = nc[0]; h.n_edges = n_edges; h.n_nodes = n_nodes;
+        h.in_off = ec[2]; h.n_in = N; h.slots = total; h.pad = 0;
+        *hs = h;
+        // update_counter (Kernels.cu:128-149), H-hop layout: nc[1] == n_nodes, ec[1] == n_edges
+        const int32_t hh = op_id / 2;
+        nc[0] += n_nodes;
+        nc[3 + 2 * hh] = nc[1 + 2 * hh] + nc[2 + 2 * hh];
+        nc[4 + 2 * hh] = n_nodes;
+        if (hh == hops) nc[5 + 2 * hh] = nc[3 + 2 * hh] + nc[4 + 2 * hh];
+        nc[1] = 0;
+        nc[2] = n_edges;
+        ec[2 + hh] = (hh == 1 ? ec[3] : ec[1 + hh]) + n_edges;
+        ec[2] = ec[0];
+        ec[0] += n_edges;
+        ec[1] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S3 pass 4 -- ordered compaction: edges, new nodes, dst-side COO offsets
+// ------------------------------------------------------------------------------------------------
+struct WriteArgs {
+    const HopState* hs;
+    const int32_t* cand;
+    const int32_t* tile_edge;
+    const int32_t* tile_node;
+    int32_t* sampled_ids;
+    int32_t* agg_src_ids;
+    int32_t* agg_src_off;
+    int32_t* agg_dst_off;
+    uint32_t* pos_map;
+    FastDiv fdiv;
+    int32_t op_id;
+};
+
+__global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
+{
+    constexpr int S = kTile / kBlock, W = kBlock / 64;
+    __shared__ int32_t s_e[S * W];
+    __shared__ int32_t s_n[S * W];
+    const HopState h = *a.hs;
+    const int32_t total = h.slots;
+    const int32_t n_tiles = (total + kTile - 1) / kTile;
+    const int lane = lane_id(), wave = wave_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int32_t c[S], re[S], rn[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
+            c[s] = (idx < total) ? a.cand[idx] : -1;
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const bool valid = c[s] != -1;
+            const bool isnew = valid && c[s] < 0;
+            const unsigned long long be = __ballot(valid), bn = __ballot(isnew);
+            re[s] = __popcll(be & lt);
+            rn[s] = __popcll(bn & lt);
+            if (lane == 0) { s_e[s * W + wave] = __popcll(be); s_n[s * W + wave] = __popcll(bn); }
+        }
+        __syncthreads();
+        const int32_t ebase = h.edge_base + a.tile_edge[tile];
+        const int32_t nbase = h.node_base + a.tile_node[tile];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (c[s] == -1) continue;
+            int32_t pe = 0, pn = 0;
+            for (int q = 0; q < s * W + wave; q++) { pe += s_e[q]; pn += s_n[q]; }
+            const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
+            const int32_t dst = (int32_t)((uint32_t)c[s] & 0x7FFFFFFFu);
+            const int32_t e = ebase + pe + re[s];
+            a.agg_src_ids[e] = dst;
+            // dst-side offset = position of the slot's source node: hop 1 sources are the seeds
+            // (position == index), later hops' sources are the previous hop's edge endpoints whose
+            // positions are that hop's src-side offsets.  Same value as position_map[src]
+            // (construct_graph, Kernels.cu:457-461) without the random read.
+            const int32_t i = (int32_t)fdiv((uint32_t)idx, a.fdiv);
+            a.agg_dst_off[e] = (a.op_id == 2) ? i : a.agg_src_off[h.in_off + i];
+            if (c[s] < 0) {
+                const int32_t p = nbase + pn + rn[s];
+                a.sampled_ids[p] = dst;
+                a.pos_map[dst] = (uint32_t)p;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// S4 (src side): agg_src_off[e] = position of the sampled neighbour (construct_graph, Kernels.cu:456-460)
+__global__ __launch_bounds__(kBlock) void k_resolve(const HopState* __restrict__ hs,
+                                                    const int32_t* __restrict__ agg_src_ids,
+                                                    const uint32_t* __restrict__ pos_map,
+                                                    int32_t* __restrict__ agg_src_off)
+{
+    const int32_t base = hs->edge_base, n = hs->n_edges;
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x)
+        agg_src_off[base + i] = (int32_t)pos_map[agg_src_ids[base + i]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// S6: stand-alone lookups (API parity with FindFeat / FindTopo; the hot path fuses them)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_find_feat(const int32_t* __restrict__ sampled_ids,
+                                                      int32_t* __restrict__ cache_offset,
+                                                      const int32_t* __restrict__ nc, int32_t off_idx,
+                                                      int32_t size_idx, const int32_t* __restrict__ feat_map)
+{
+    const int32_t off = nc[off_idx], n = nc[size_idx];
+    for (int32_t r = threadIdx.x + blockDim.x * blockIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        int32_t id = sampled_ids[off + r];
+        cache_offset[r] = (id < 0 || !feat_map) ? -1 : feat_map[id];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_find_topo(const int32_t* __restrict__ input_ids,
+                                                      int8_t* __restrict__ part_index,
+                                                      int32_t* __restrict__ part_offset, int32_t n,
+                                                      const int8_t* __restrict__ owner,
+                                                      const int32_t* __restrict__ row)
+{
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int32_t id = input_ids[i];
+        bool ok = id >= 0 && owner;
+        part_index[i] = ok ? owner[id] : (int8_t)-1;
+        part_offset[i] = ok ? row[id] : -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S5: feature gather from the unified cache / the backing table
+// ------------------------------------------------------------------------------------------------
+struct GatherKArgs {
+    GatherArgs g;
+    FastDiv div_c;   // / chunks-per-row
+    FastDiv div_cap; // / cache_capacity
+};
+
+template <typename VT, int UNROLL>
+__global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
+{
+    constexpr int VEC = sizeof(VT) / 4;
+    const GatherArgs& g = a.g;
+    const int32_t off = g.off_idx < 0 ? 0 : g.nc[g.off_idx];
+    const int32_t rows = g.nc[g.size_idx];
+    const int32_t C = g.F / VEC;
+    const int64_t total = (int64_t)rows * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += stride * UNROLL) {
+        const VT* src[UNROLL];
+        VT val[UNROLL];
+        int64_t dsti[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            const int64_t q = q0 + u * stride;
+            src[u] = nullptr;
+            dsti[u] = 0;
+            if (q < total) {
+                const uint32_t r = fdiv((uint32_t)q, a.div_c); // rows*C < 2^31 is checked by the launcher
+                const uint32_t ch = (uint32_t)q - r * (uint32_t)C;
+                if (g.dst_rows > 0 && off + (int32_t)r >= g.dst_rows) continue; // never write past the buffer
+                const int32_t id = g.sampled_ids[off + (int32_t)r];
+                int32_t gidx = -1;
+                if (g.feat_map && id >= 0) gidx = g.feat_map[id]; // FindFeat fused
+                if (gidx >= 0) {
+                    const uint32_t didx = fdiv((uint32_t)gidx, a.div_cap);
+                    const uint32_t fidx = (uint32_t)gidx - didx * (uint32_t)g.cache_capacity;
+                    src[u] = reinterpret_cast<const VT*>(g.cache[didx] + (int64_t)fidx * g.F) + ch;
+                } else if (id >= 0) {
+                    src[u] = reinterpret_cast<const VT*>(g.table + (int64_t)(id % g.total_num_nodes) * g.F) + ch;
+                }
+                dsti[u] = ((int64_t)(off + (int32_t)r) * g.F) / VEC + ch;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+            if (src[u]) val[u] = *src[u];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
+            if (src[u]) reinterpret_cast<VT*>(g.dst)[dsti[u]] = val[u];
+    }
+}
+
+// S7: HotnessMeasure (GPUCache.cu:227-235)
+__global__ __launch_bounds__(kBlock) void k_hotness(const int32_t* __restrict__ ids, const int32_t* __restrict__ nc,
+                                                    int32_t hops, unsigned long long* __restrict__ access,
+                                                    int32_t* __restrict__ max_ids)
+{
+    const int32_t n = hops > 0 ? total_nodes(nc, hops) : nc[0];
+    // max_ids_ (GPUCache.cu:294-296) kept on the device: no blocking D2H per batch
+    if (max_ids && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(max_ids, n);
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int32_t cid = ids[i];
+        if (cid >= 0) atomicAdd(access + cid, 1ull);
+    }
+}
+
+__global__ void k_rng_probe(const int32_t* idx, const int32_t* deg, int32_t* k, int32_t n)
+{
+    int32_t i = threadIdx.x + blockDim.x * blockIdx.x;
+    if (i < n) k[i] = sample_index(powmod31(kA, (uint64_t)idx[i] + 1ull), deg[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// cache construction kernels (one-off; S8 / S9)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_aggregate_access(unsigned long long* agg, const unsigned long long* add, int32_t n)
+{   // GPUCache.cu:44-48
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) agg[i] += add[i];
+}
+__global__ void k_iota(int32_t* out, int32_t n)
+{   // init_cache_order, GPUCache.cu:50-54
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = i;
+}
+__global__ void k_fill_i32(int32_t* p, int32_t v, int64_t n)
+{
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_fill_i8(int8_t* p, int8_t v, int64_t n)
+{
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+// InitPair (GPUCache.cu:103-108) scattered into the direct-mapped table: rank t -> slot
+__global__ void k_build_feat_map(int32_t* feat_map, const int32_t* QF, int32_t capacity, int32_t Kg, int32_t V)
+{
+    const int64_t n = min((int64_t)capacity * Kg, (int64_t)V);
+    for (int64_t t = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        feat_map[QF[t]] = (int32_t)((t % Kg) * capacity + t / Kg);
+}
+// InitIndexPair / InitOffsetPair (GPUCache.cu:88-100)
+__global__ void k_build_topo_map(int8_t* owner, int32_t* row, const int32_t* QT, int32_t capacity, int32_t Kg,
+                                 int32_t Ki, int32_t V)
+{
+    const int64_t n = min((int64_t)capacity * Kg, (int64_t)V);
+    for (int64_t t = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        owner[QT[t]] = (int8_t)(t % Kg + Ki * Kg);
+        row[QT[t]] = (int32_t)(t / Kg);
+    }
+}
+// FeatFillUp (GPUCache.cu:200-205): cache row r of clique GPU Ki = features of QF[r*Kg + Ki]
+__global__ void k_feat_fill_up(int32_t capacity, int32_t F, float* cache, const float* table, const int32_t* QF,
+                               int32_t Kg, int32_t Ki, int32_t V)
+{
+    const int64_t n = (int64_t)capacity * F;
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / F, t = r * Kg + Ki;
+        if (t >= V) continue;
+        cache[i] = table[(int64_t)QF[t] * F + i % F];
+    }
+}
+// GetNeighborCount (GPU_Memory_Graph_Storage.cu:14-20)
+__global__ void k_neighbor_count(const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
+                                 const int64_t* indptr, int64_t* count_out)
+{
+    for (int32_t r = threadIdx.x + blockDim.x * blockIdx.x; r < capacity; r += gridDim.x * blockDim.x) {
+        const int64_t t = (int64_t)r * Kg + Ki;
+        int64_t c = 0;
+        if (t < V) { int32_t id = QT[t]; c = indptr[id + 1] - indptr[id]; }
+        count_out[r] = c;
+    }
+}
+// TopoFillUp (GPU_Memory_Graph_Storage.cu:22-34); one wave per row, lanes stride the neighbours
+__global__ void k_topo_fill_up(const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
+                               const int64_t* indptr, const int32_t* indices, const int64_t* frag_indptr,
+                               int32_t* frag_indices)
+{
+    const int32_t wave = (threadIdx.x + blockDim.x * blockIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int32_t r = wave; r < capacity; r += nwaves) {
+        const int64_t t = (int64_t)r * Kg + Ki;
+        if (t >= V) continue;
+        const int32_t id = QT[t];
+        const int64_t s = indptr[id], c = indptr[id + 1] - s, o = frag_indptr[r];
+        for (int64_t i = lane_id(); i < c; i += 64) frag_indices[o + i] = indices[s + i];
+    }
+}
+// GetEdgeMem (GPUCache.cu:35-41)
+__global__ void k_edge_mem(const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)
+{
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        int32_t id = order[i];
+        edge_mem[i] = (uint64_t)(sizeof(int64_t) + sizeof(int32_t) * (indptr[id + 1] - indptr[id]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: launch wrappers
+// ------------------------------------------------------------------------------------------------
+FastDiv::FastDiv(uint32_t div)
+{
+    d = div ? div : 1;
+    if (d == 1) { m = 0; s = 0; return; }
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    m = (uint32_t)(((1ull << (31 + l)) / d) + 1ull);
+    s = 31 + l;
+}
+
+static int g_cu_count = 0;
+static int cu_count()
+{
+    if (!g_cu_count) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            g_cu_count = p.multiProcessorCount;
+        if (g_cu_count <= 0) g_cu_count = 256;
+    }
+    return g_cu_count;
+}
+static inline int grid_for(int64_t work_items, int per_block, int blocks_per_cu = 8)
+{
+    int64_t need = (work_items + per_block - 1) / per_block;
+    int64_t cap = (int64_t)cu_count() * blocks_per_cu;
+    if (need < 1) need = 1;
+    return (int)(need < cap ? need : cap);
+}
+
+// 48271^(m+1) table for m < kTile, one copy per physical device
+static uint32_t* pow_table()
+{
+    static uint32_t* tabs[64] = {nullptr};
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (!tabs[dev]) {
+        std::vector<uint32_t> h(kTile);
+        uint32_t x = 1;
+        for (int m = 0; m < kTile; m++) { x = mulmod31(x, kA); h[m] = x; }
+        HIP_CHECK(hipMalloc(&tabs[dev], kTile * sizeof(uint32_t)));
+        HIP_CHECK(hipMemcpy(tabs[dev], h.data(), kTile * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    return tabs[dev];
+}
+
+void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size, int32_t counter,
+                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, uint32_t* pos_map,
+                 int32_t* nc, int32_t* ec)
+{
+    int blocks = size > 0 ? (size - 1) / kBlock + 1 : 1;
+    k_seed<<<blocks, kBlock, 0, s>>>(batch_ids, labels, size, counter, all_ids, all_labels, total_cap, pos_map, nc, ec);
+    HIP_CHECK_LAST();
+}
+
+void launch_reset_pos_map(hipStream_t s, uint32_t* pos_map, const int32_t* ids, const int32_t* nc, int32_t hops,
+                          int32_t bound)
+{
+    k_reset_pos_map<<<grid_for(bound, kBlock), kBlock, 0, s>>>(pos_map, ids, nc, hops);
+    HIP_CHECK_LAST();
+}
+
+void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers& b, int32_t count, int32_t op_id,
+                       int32_t hops, int32_t slots_bound, bool is_presc)
+{
+    if (count <= 0 || slots_bound <= 0) { LEGION_ARG_ERROR("GPU_Random_Sampling: empty hop"); return; }
+    const int max_tiles = (slots_bound + kTile - 1) / kTile;
+    const int grid = grid_for(max_tiles, 1, 8);
+    SampleArgs a;
+    a.csr = csr;
+    a.sampled_ids = b.sampled_ids; a.agg_src_ids = b.agg_src_ids; a.nc = b.nc; a.ec = b.ec;
+    a.pos_map = b.pos_map; a.cand = b.cand; a.tile_edge = b.tile_edge;
+    a.edge_access_time = b.edge_access_time;
+    a.pow_tab = pow_table();
+    a.a_tile = powmod31(kA, kTile);
+    a.a_step = powmod31(kA, (uint64_t)kTile * (uint64_t)grid);
+    a.fdiv = FastDiv((uint32_t)count);
+    a.count = count; a.op_id = op_id;
+    const bool part = csr.topo_owner != nullptr;
+    if (is_presc) k_sample<true, false><<<grid, kBlock, 0, s>>>(a);
+    else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
+    else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
+    HIP_CHECK_LAST();
+    k_mark<<<grid, kBlock, 0, s>>>(b.nc, count, b.pos_map, b.cand, b.tile_node);
+    HIP_CHECK_LAST();
+    k_scan_tiles<<<1, kScanBlock, 0, s>>>(b.nc, b.ec, count, op_id, hops, b.tile_edge, b.tile_node, b.hop_state);
+    HIP_CHECK_LAST();
+    WriteArgs w;
+    w.hs = b.hop_state; w.cand = b.cand; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
+    w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
+    w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id;
+    k_write<<<grid, kBlock, 0, s>>>(w);
+    HIP_CHECK_LAST();
+    k_resolve<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.hop_state, b.agg_src_ids, b.pos_map, b.agg_src_off);
+    HIP_CHECK_LAST();
+}
+
+void launch_find_feat(hipStream_t s, const int32_t* sampled_ids, int32_t* cache_offset, const int32_t* nc,
+                      int32_t op_id, const int32_t* feat_map, int32_t bound)
+{
+    const int l = (op_id - 1) / 2;
+    k_find_feat<<<grid_for(bound, kBlock), kBlock, 0, s>>>(sampled_ids, cache_offset, nc, 3 + 2 * l, 4 + 2 * l, feat_map);
+    HIP_CHECK_LAST();
+}
+
+void launch_find_topo(hipStream_t s, const int32_t* input_ids, int8_t* part_index, int32_t* part_offset,
+                      int32_t batch_size, const int8_t* topo_owner, const int32_t* topo_row)
+{
+    if (batch_size <= 0) return;
+    k_find_topo<<<grid_for(batch_size, kBlock), kBlock, 0, s>>>(input_ids, part_index, part_offset, batch_size, topo_owner, topo_row);
+    HIP_CHECK_LAST();
+}
+
+void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
+{
+    if (g.F <= 0 || rows_bound <= 0) return;
+    GatherKArgs a;
+    a.g = g;
+    a.div_cap = FastDiv((uint32_t)(g.cache_capacity > 0 ? g.cache_capacity : 1));
+    bool vec4 = (g.F % 4 == 0) && (((uintptr_t)g.table | (uintptr_t)g.dst) % 16 == 0);
+    for (int i = 0; vec4 && i < kMaxParts; i++)
+        if (g.cache[i] && ((uintptr_t)g.cache[i] % 16)) vec4 = false;
+    const int C = vec4 ? g.F / 4 : g.F;
+    if ((int64_t)rows_bound * C >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
+    a.div_c = FastDiv((uint32_t)C);
+    constexpr int U = 4;
+    const int grid = grid_for((int64_t)rows_bound * C, kBlock * U, 8);
+    if (vec4) k_gather<float4, U><<<grid, kBlock, 0, s>>>(a);
+    else k_gather<float, U><<<grid, kBlock, 0, s>>>(a);
+    HIP_CHECK_LAST();
+}
+
+void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_t hops, unsigned long long* access,
+                    int32_t* max_ids, int32_t bound)
+{
+    k_hotness<<<grid_for(bound, kBlock), kBlock, 0, s>>>(ids, nc, hops, access, max_ids);
+    HIP_CHECK_LAST();
+}
+
+void launch_rng_probe(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* k, int32_t n)
+{
+    if (n <= 0) return;
+    k_rng_probe<<<(n + 255) / 256, 256, 0, s>>>(idx, deg, k, n);
+    HIP_CHECK_LAST();
+}
+
+void launch_aggregate_access(hipStream_t s, unsigned long long* agg, const unsigned long long* add, int32_t n)
+{
+    k_aggregate_access<<<grid_for(n, 256), 256, 0, s>>>(agg, add, n);
+    HIP_CHECK_LAST();
+}
+void launch_iota(hipStream_t s, int32_t* out, int32_t n)
+{
+    k_iota<<<grid_for(n, 256), 256, 0, s>>>(out, n);
+    HIP_CHECK_LAST();
+}
+void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n)
+{
+    if (n <= 0) return;
+    k_fill_i32<<<grid_for(n, 256), 256, 0, s>>>(p, v, n);
+    HIP_CHECK_LAST();
+}
+void launch_fill_i8(hipStream_t s, int8_t* p, int8_t v, int64_t n)
+{
+    if (n <= 0) return;
+    k_fill_i8<<<grid_for(n, 256), 256, 0, s>>>(p, v, n);
+    HIP_CHECK_LAST();
+}
+void launch_build_feat_map(hipStream_t s, int32_t* feat_map, const int32_t* QF, int32_t capacity, int32_t Kg, int32_t V)
+{
+    launch_fill_i32(s, feat_map, -1, V);
+    if (capacity <= 0) return;
+    k_build_feat_map<<<grid_for((int64_t)capacity * Kg, 256), 256, 0, s>>>(feat_map, QF, capacity, Kg, V);
+    HIP_CHECK_LAST();
+}
+void launch_build_topo_map(hipStream_t s, int8_t* owner, int32_t* row, const int32_t* QT, int32_t capacity, int32_t Kg,
+                           int32_t Ki, int32_t V)
+{
+    launch_fill_i8(s, owner, (int8_t)-1, V);
+    launch_fill_i32(s, row, -1, V);
+    if (capacity <= 0) return;
+    k_build_topo_map<<<grid_for((int64_t)capacity * Kg, 256), 256, 0, s>>>(owner, row, QT, capacity, Kg, Ki, V);
+    HIP_CHECK_LAST();
+}
+void launch_feat_fill_up(hipStream_t s, int32_t capacity, int32_t F, float* cache, const float* table, const int32_t* QF,
+                         int32_t Kg, int32_t Ki, int32_t V)
+{
+    if (capacity <= 0) return;
+    k_feat_fill_up<<<grid_for((int64_t)capacity * F, 256), 256, 0, s>>>(capacity, F, cache, table, QF, Kg, Ki, V);
+    HIP_CHECK_LAST();
+}
+void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
+                           const int64_t* indptr, int64_t* count_out)
+{
+    if (capacity <= 0) return;
+    k_neighbor_count<<<grid_for(capacity, 256), 256, 0, s>>>(QT, Kg, Ki, capacity, V, indptr, count_out);
+    HIP_CHECK_LAST();
+}
+void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
+                         const int64_t* indptr, const int32_t* indices, const int64_t* frag_indptr,
+                         int32_t* frag_indices)
+{
+    if (capacity <= 0) return;
+    k_topo_fill_up<<<grid_for((int64_t)capacity * 64, 256), 256, 0, s>>>(QT, Kg, Ki, capacity, V, indptr, indices, frag_indptr, frag_indices);
+    HIP_CHECK_LAST();
+}
+void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)
+{
+    k_edge_mem<<<grid_for(V, 256), 256, 0, s>>>(order, edge_mem, V, indptr);
+    HIP_CHECK_LAST();
+}
+
+// thrust::sort_by_key(keys, ids, greater) (GPUCache.cu:631,651).  The reference's sort is not
+// stable, so the order among equal keys is unspecified there; we use a stable descending radix
+// sort seeded with ascending ids => ties in ascending id order (the oracle's documented rule).
+void sort_by_hotness_desc(hipStream_t s, unsigned long long* keys, int32_t* ids, int32_t n)
+{
+    if (n <= 0) return;
+    unsigned long long* keys_out = nullptr;
+    int32_t* ids_out = nullptr;
+    HIP_CHECK(hipMalloc(&keys_out, (size_t)n * sizeof(unsigned long long)));
+    HIP_CHECK(hipMalloc(&ids_out, (size_t)n * sizeof(int32_t)));
+    size_t tmp_bytes = 0;
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, keys, keys_out, ids, ids_out, n, 0, 64, s));
+    void* tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(tmp, tmp_bytes, keys, keys_out, ids, ids_out, n, 0, 64, s));
+    HIP_CHECK(hipMemcpyAsync(keys, keys_out, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(ids, ids_out, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipFree(tmp));
+    HIP_CHECK(hipFree(keys_out));
+    HIP_CHECK(hipFree(ids_out));
+}
+
+template <typename T>
+static void inclusive_scan_t(hipStream_t s, const T* in, T* out, int32_t n)
+{
+    if (n <= 0) return;
+    size_t tmp_bytes = 0;
+    HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, in, out, n, s));
+    void* tmp = nullptr;
+    HIP_CHECK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    HIP_CHECK(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, in, out, n, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    HIP_CHECK(hipFree(tmp));
+}
+void inclusive_scan_u64(hipStream_t s, const uint64_t* in, uint64_t* out, int32_t n) { inclusive_scan_t(s, in, out, n); }
+void inclusive_scan_i64(hipStream_t s, const int64_t* in, int64_t* out, int32_t n) { inclusive_scan_t(s, in, out, n); }
+
+} // namespace legion

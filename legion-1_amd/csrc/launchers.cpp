@@ -1,0 +1,299 @@
+// launchers.cpp -- the extern "C" operator launchers of the reference (src/Kernels.cuh:47-93,
+// Kernels.cu:162-232,567-659,706-805) on top of kernels.hip, plus the Operator plugin classes
+// (src/Operator.h:4-27, Operator.cu:10-124).
+#include "internal.h"
+
+#include <iostream>
+
+using namespace legion;
+
+static inline int pool_dev(const GPUMemoryPool* p)
+{
+    if (p->device_id >= 0) return p->device_id;
+    int d = 0;
+    (void)hipGetDevice(&d); // reference: dev_id = cudaGetDevice() (Kernels.cu:577-578)
+    return d;
+}
+
+static bool pool_ready(const GPUMemoryPool* p, const char* who)
+{
+    if (!p || !p->owns_scratch) { LEGION_ARG_ERROR((std::string(who) + ": GPUMemoryPool_AllocateScratch was not called").c_str()); return false; }
+    const int q = p->current_pipe;
+    if (!p->sampled_ids[q] || !p->labels[q] || !p->agg_src_off[q] || !p->agg_dst_off[q] || !p->node_counter[q] || !p->edge_counter[q]) {
+        LEGION_ARG_ERROR((std::string(who) + ": output buffers of the current pipe are not set").c_str());
+        return false;
+    }
+    return true;
+}
+
+extern "C" {
+
+// batch_generator_kernel, Kernels.cu:162-232
+void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cache, GPUMemoryPool* memorypool,
+                            int32_t batch_size, int32_t counter, int32_t part_id, int32_t dev_id, int32_t mode)
+{
+    (void)cache; (void)part_id;
+    if (!noder || !pool_ready(memorypool, "batch_generator_kernel")) return;
+    hipStream_t s = (hipStream_t)strm_hdl;
+    int32_t* all_ids = nullptr;
+    int32_t* all_labels = nullptr;
+    int32_t total_cap = 0;
+    if (mode == LEGION_TRAINMODE) {
+        all_ids = GPUNodeStorage_GetTrainingSetIds(noder, dev_id);
+        all_labels = GPUNodeStorage_GetTrainingLabels(noder, dev_id);
+        total_cap = GPUNodeStorage_TrainingSetSize(noder, dev_id);
+    } else if (mode == LEGION_VALIDMODE) {
+        all_ids = GPUNodeStorage_GetValidationSetIds(noder, dev_id);
+        all_labels = GPUNodeStorage_GetValidationLabels(noder, dev_id);
+        total_cap = GPUNodeStorage_ValidationSetSize(noder, dev_id);
+    } else if (mode == LEGION_TESTMODE) {
+        all_ids = GPUNodeStorage_GetTestingSetIds(noder, dev_id);
+        all_labels = GPUNodeStorage_GetTestingLabels(noder, dev_id);
+        total_cap = GPUNodeStorage_TestingSetSize(noder, dev_id);
+    } else {
+        std::cout << "invalid mode: " << mode << "\n";
+    }
+    if (all_ids == nullptr) { std::cout << "invalid src id ptr\n"; return; }
+    if (all_labels == nullptr) { std::cout << "invalid label ptr\n"; return; }
+
+    GPUMemoryPool* p = memorypool;
+    p->device_id = dev_id;
+    // ClearPosMap of a batch whose planner op never ran (any mode)
+    if (p->dirty_ids) {
+        launch_reset_pos_map(s, p->pos_map, p->dirty_ids, p->dirty_nc, p->hops, p->dirty_bound);
+        p->dirty_ids = nullptr;
+    }
+    // Kernels.cu:224
+    int32_t size = ((batch_size * (counter + 1)) >= total_cap) ? (total_cap - batch_size * counter) : batch_size;
+    if (size > p->batch_size) { LEGION_ARG_ERROR("batch_generator_kernel: batch larger than the pool was sized for"); return; }
+    const int q = p->current_pipe;
+    launch_seed(s, p->sampled_ids[q], p->labels[q], size, counter, all_ids, all_labels, total_cap, p->pos_map,
+                p->node_counter[q], p->edge_counter[q]);
+    p->bound_n = size > 0 ? size : 0;
+    p->bound_nodes = p->bound_n;
+    p->dirty_ids = p->sampled_ids[q];
+    p->dirty_nc = p->node_counter[q];
+    p->dirty_bound = p->num_ids;
+}
+
+// GPU_Random_Sampling, Kernels.cu:567-659
+void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache, GPUMemoryPool* memorypool,
+                         int32_t count, int32_t op_id, int is_presc)
+{
+    if (graph == nullptr) { std::cout << "invalid storage ptr\n"; return; }
+    if (!pool_ready(memorypool, "GPU_Random_Sampling")) return;
+    GPUMemoryPool* p = memorypool;
+    const int hop = op_id / 2;
+    if (op_id < 2 || (op_id & 1) || hop > p->hops) { LEGION_ARG_ERROR("GPU_Random_Sampling: op_id must be 2,4,..,2*hops"); return; }
+    const int dev = pool_dev(p);
+    const int P = graph->partition_count;
+    if (dev < 0 || dev >= P) { LEGION_ARG_ERROR("GPU_Random_Sampling: device outside the partition table"); return; }
+    const int64_t slots = (int64_t)p->bound_n * count;
+    if (slots > p->max_slots) { LEGION_ARG_ERROR("GPU_Random_Sampling: fan-out exceeds what the pool was sized for"); return; }
+    if (slots <= 0) return;
+
+    CsrTables csr;
+    for (int i = 0; i <= kMaxParts; i++) { csr.indptr[i] = nullptr; csr.indices[i] = nullptr; }
+    csr.partition_count = P;
+    csr.indptr[P] = graph->csr_node_index_cpu;
+    csr.indices[P] = graph->csr_dst_node_ids_cpu;
+    csr.topo_owner = nullptr;
+    csr.topo_row = nullptr;
+    SamplerBuffers b;
+    const int q = p->current_pipe;
+    b.sampled_ids = p->sampled_ids[q]; b.agg_src_ids = p->agg_src_ids; b.agg_src_off = p->agg_src_off[q];
+    b.agg_dst_off = p->agg_dst_off[q]; b.nc = p->node_counter[q]; b.ec = p->edge_counter[q];
+    b.pos_map = p->pos_map; b.cand = p->cand; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
+    b.hop_state = p->hop_state; b.edge_access_time = nullptr;
+    if (is_presc) {
+        // kernel_pre_sampler_optimized: host CSR only + topology hotness (Kernels.cu:636-649)
+        if (!cache || dev >= cache->device_count || !cache->ctl[dev]->edge_access_time) { LEGION_ARG_ERROR("GPU_Random_Sampling: pre-sampling needs an initialised cache controller"); return; }
+        b.edge_access_time = cache->ctl[dev]->edge_access_time;
+    } else if (cache && dev < cache->device_count && cache->ctl[dev]->topo_owner && cache->ctl[dev]->edge_capacity > 0) {
+        bool any = false;
+        for (int g = 0; g < P; g++) {
+            csr.indptr[g] = graph->view_indptr[dev][g];
+            csr.indices[g] = graph->view_indices[dev][g];
+            any = any || csr.indptr[g];
+        }
+        if (any) { csr.topo_owner = cache->ctl[dev]->topo_owner; csr.topo_row = cache->ctl[dev]->topo_row; }
+    }
+    launch_sample_hop((hipStream_t)strm_hdl, csr, b, count, op_id, p->hops, (int32_t)slots, is_presc != 0);
+    p->bound_n = (int32_t)slots;          // next hop expands every sampled edge endpoint
+    p->bound_nodes += (int32_t)slots;
+}
+
+static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* p, int32_t dev_id,
+                          int off_idx, int size_idx, int32_t rows_bound)
+{
+    const int32_t F = noder->float_attr_len;
+    if (F < 0) std::cout << "error feature len\n"; // Kernels.cu:719-721
+    const int q = p->current_pipe;
+    if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return; }
+    GatherArgs g;
+    g.table = noder->float_attrs;
+    for (int i = 0; i < kMaxParts; i++) g.cache[i] = nullptr;
+    g.feat_map = nullptr;
+    g.cache_capacity = 1;
+    g.F = F;
+    g.total_num_nodes = noder->total_num_nodes;
+    g.sampled_ids = p->sampled_ids[q];
+    g.nc = p->node_counter[q];
+    g.dst = p->float_features[q];
+    g.off_idx = off_idx;
+    g.size_idx = size_idx;
+    g.dst_rows = p->feature_rows;
+    if (cache && dev_id >= 0 && dev_id < cache->device_count && cache->ctl[dev_id]->feat_map && cache->ctl[dev_id]->node_capacity > 0) {
+        const int Kg = cache->Kg, Ki = dev_id / Kg;
+        g.feat_map = cache->ctl[dev_id]->feat_map;
+        g.cache_capacity = cache->ctl[dev_id]->node_capacity;
+        for (int j = 0; j < Kg; j++) g.cache[j] = cache->float_feature_cache[Ki * Kg + j]; // d_float_feature_cache_ptr_, GPUCache.cu:809-816
+    }
+    if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return; }
+    launch_gather((hipStream_t)strm_hdl, g, rows_bound);
+}
+
+// get_feature_kernel, Kernels.cu:706-748.  op_id 2l+1 gathers level l.
+void get_feature_kernel(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool,
+                        int32_t dev_id, int32_t op_id, int in_memory)
+{
+    if (!noder || !pool_ready(memorypool, "get_feature_kernel")) return;
+    const int l = (op_id - 1) / 2;
+    if (op_id < 1 || !(op_id & 1) || l > memorypool->hops) { LEGION_ARG_ERROR("get_feature_kernel: op_id must be 1,3,..,2*hops+1"); return; }
+    if (!in_memory) return; // the reference only launches the in-memory path (Kernels.cu:737-746)
+    gather_common(strm_hdl, cache, noder, memorypool, dev_id, 3 + 2 * l, 4 + 2 * l, memorypool->level_bound[l]);
+}
+
+void get_feature_kernel_all(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool,
+                            int32_t dev_id, int in_memory)
+{
+    if (!noder || !pool_ready(memorypool, "get_feature_kernel_all")) return;
+    if (!in_memory) return;
+    gather_common(strm_hdl, cache, noder, memorypool, dev_id, -1, 0, memorypool->num_ids); // rows [0, nc[0])
+}
+
+// make_update_plan, Kernels.cu:758-783
+void make_update_plan(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache, GPUMemoryPool* memorypool,
+                      int32_t dev_id, int32_t mode)
+{
+    (void)graph;
+    if (!pool_ready(memorypool, "make_update_plan")) return;
+    GPUMemoryPool* p = memorypool;
+    const int q = p->current_pipe;
+    hipStream_t s = (hipStream_t)strm_hdl;
+    if (mode == LEGION_TRAINMODE && cache) // CacheProfiling: HotnessMeasure during pre-sampling
+        GPUCache_CacheProfiling(cache, p->sampled_ids[q], p->node_counter[q], strm_hdl, dev_id);
+    // ClearPosMap.  The reference clears in train mode only because its bitmap guards stale
+    // entries; our single table must be clean before the next batch in every mode.
+    launch_reset_pos_map(s, p->pos_map, p->sampled_ids[q], p->node_counter[q], p->hops, p->num_ids);
+    if (p->dirty_ids == p->sampled_ids[q]) p->dirty_ids = nullptr;
+}
+
+// update_cache, Kernels.cu:785-805: the reference body is commented out -- a no-op.
+void update_cache(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id,
+                  int32_t mode)
+{
+    (void)strm_hdl; (void)cache; (void)noder; (void)memorypool; (void)dev_id; (void)mode;
+}
+
+} // extern "C"
+
+// =================================== Operator plugin API ============================================
+struct Operator {
+    virtual ~Operator() = default;
+    virtual void run(OpParams* params) = 0;
+};
+
+namespace {
+
+inline void record(OpParams* p)
+{
+    if (p->event) HIP_CHECK(hipEventRecord((hipEvent_t)p->event, (hipStream_t)p->stream));
+}
+
+class Batch_Generator : public Operator { // Operator.cu:10-31
+public:
+    explicit Batch_Generator(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        GPUNodeStorage* noder = (GPUNodeStorage*)params->noder;
+        GPUCache* cache = (GPUCache*)params->cache;
+        GPUMemoryPool* memorypool = (GPUMemoryPool*)params->memorypool;
+        int32_t mode = GPUMemoryPool_GetCurrentMode(memorypool);
+        int32_t iter = GPUMemoryPool_GetIter(memorypool);
+        IPCEnv* env = (IPCEnv*)params->env;
+        int32_t device_id = params->device_id;
+        int32_t batch_size = IPCEnv_GetCurrentBatchsize(env, device_id, mode);
+        batch_generator_kernel(params->stream, noder, cache, memorypool, batch_size, iter, device_id, device_id, mode);
+        record(params);
+    }
+private:
+    int op_id_;
+};
+
+class Random_Sampler : public Operator { // Operator.cu:37-55
+public:
+    explicit Random_Sampler(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        GPU_Random_Sampling(params->stream, (GPUGraphStorage*)params->graph, (GPUCache*)params->cache,
+                            (GPUMemoryPool*)params->memorypool, params->neighbor_count, op_id_, params->is_presc);
+        record(params);
+    }
+private:
+    int op_id_;
+};
+
+class Feature_Extractor : public Operator { // Operator.cu:61-76 (records no event)
+public:
+    explicit Feature_Extractor(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        get_feature_kernel(params->stream, (GPUCache*)params->cache, (GPUNodeStorage*)params->noder,
+                           (GPUMemoryPool*)params->memorypool, params->device_id, op_id_, params->in_memory);
+    }
+private:
+    int op_id_;
+};
+
+class Cache_Planner : public Operator { // Operator.cu:82-97
+public:
+    explicit Cache_Planner(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        GPUMemoryPool* memorypool = (GPUMemoryPool*)params->memorypool;
+        int mode = GPUMemoryPool_GetCurrentMode(memorypool);
+        make_update_plan(params->stream, (GPUGraphStorage*)params->graph, (GPUCache*)params->cache, memorypool,
+                         params->device_id, mode);
+        record(params);
+    }
+private:
+    int op_id_;
+};
+
+class Cache_Updater : public Operator { // Operator.cu:103-119
+public:
+    explicit Cache_Updater(int op_id) : op_id_(op_id) {}
+    void run(OpParams* params) override
+    {
+        GPUMemoryPool* memorypool = (GPUMemoryPool*)params->memorypool;
+        int mode = GPUMemoryPool_GetCurrentMode(memorypool);
+        update_cache(params->stream, (GPUCache*)params->cache, (GPUNodeStorage*)params->noder, memorypool,
+                     params->device_id, mode);
+        record(params);
+    }
+private:
+    int op_id_;
+};
+
+} // namespace
+
+extern "C" {
+Operator* NewBatchGenerator(int op_id) { return new Batch_Generator(op_id); }
+Operator* NewRandomSampler(int op_id) { return new Random_Sampler(op_id); }
+Operator* NewFeatureExtractor(int op_id) { return new Feature_Extractor(op_id); }
+Operator* NewCachePlanner(int op_id) { return new Cache_Planner(op_id); }
+Operator* NewCacheUpdater(int op_id) { return new Cache_Updater(op_id); }
+void Operator_run(Operator* op, OpParams* params) { if (op && params) op->run(params); }
+void Operator_Delete(Operator* op) { delete op; }
+}

@@ -1,0 +1,404 @@
+// runner.cpp -- per-GPU pipeline driver and the sampling server:
+//   GPURunner   src/Server.cu:163-369   (op list, 2 streams + events, RunPreSc / RunOnce)
+//   GPUServer   src/Server.cu:43-161    (boot, pre-sampling epoch, cache build, run loop)
+//   GPUGraphStore (loader)  src/GPUGraphStore.cu:30-143,190-443  (meta_config + raw files + seed split)
+// The Intel-PCM monitor of the reference (Server.h:54-135) is not rebuilt: CostModel gets its
+// transaction input from the collected hotness instead (cache.cpp).
+#include "internal.h"
+
+#include <chrono>
+#include <cstring>
+#include <fcntl.h>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+
+using namespace legion;
+
+// =========================================== Runner ======================================================
+struct Runner {
+    int32_t num_ids = 0, float_attr_len = 0;
+    GPUMemoryPool* memorypool = nullptr;
+    int current_pipe = 0, pipeline_depth = LEGION_PIPELINE_DEPTH, local_dev_id = 0, mode = 0, op_num = 0, hops = 0;
+    hipStream_t streams[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> events;
+    std::vector<Operator*> op_factory;
+    std::vector<OpParams*> op_params;
+    int32_t feature_rows = 0;
+};
+
+extern "C" {
+
+Runner* NewGPURunner(void) { return new Runner(); }
+
+// GPURunner::Initialize, Server.cu:169-271
+void Runner_Initialize(Runner* r, RunnerParams* params)
+{
+    if (!r || !params || !params->fanout || params->hops < 1 || params->hops > LEGION_MAX_HOPS) { LEGION_ARG_ERROR("Runner_Initialize: bad arguments"); return; }
+    r->local_dev_id = params->device_id;
+    DeviceGuard guard(r->local_dev_id);
+    GPUCache* cache = (GPUCache*)params->cache;
+    GPUNodeStorage* noder = (GPUNodeStorage*)params->noder;
+    IPCEnv* env = (IPCEnv*)params->env;
+    HIP_CHECK(hipStreamCreateWithFlags(&r->streams[0], hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&r->streams[1], hipStreamNonBlocking));
+    const int batch_size = IPCEnv_GetRawBatchsize(env);
+    const int hop_num = params->hops;
+    r->hops = hop_num;
+    // op list: [BatchGen, Feat, (Samp, Feat) x hops, Planner, Updater]  (Server.cu:198-207)
+    r->op_num = (hop_num + 1) * 2 + 2;
+    r->op_factory.resize(r->op_num);
+    r->op_factory[0] = NewBatchGenerator(0);
+    r->op_factory[1] = NewFeatureExtractor(1);
+    for (int i = 0; i < hop_num; i++) {
+        r->op_factory[2 * i + 2] = NewRandomSampler(2 * i + 2);
+        r->op_factory[2 * i + 3] = NewFeatureExtractor(2 * i + 3);
+    }
+    r->op_factory[r->op_num - 2] = NewCachePlanner(r->op_num - 2);
+    r->op_factory[r->op_num - 1] = NewCacheUpdater(r->op_num - 1);
+
+    r->pipeline_depth = LEGION_PIPELINE_DEPTH;
+    const int total_num_nodes = GPUNodeStorage_TotalNodeNum(noder);
+    GPUCache_InitializeCacheController(cache, r->local_dev_id, total_num_nodes);
+    r->memorypool = NewGPUMemoryPool(r->pipeline_depth);
+    GPUMemoryPool_AllocateScratch(r->memorypool, total_num_nodes, batch_size, params->fanout, hop_num);
+    r->memorypool->device_id = r->local_dev_id;
+    r->num_ids = GPUMemoryPool_NumIds(r->memorypool);
+    r->float_attr_len = GPUNodeStorage_GetFloatAttrLen(noder);
+    IPCEnv_InitializeSamplesBuffer(env, batch_size, r->num_ids, r->float_attr_len, r->local_dev_id, r->pipeline_depth);
+    IPCEnv_SetHops(env, hop_num);
+    r->current_pipe = 0;
+    for (int i = 0; i < r->pipeline_depth; i++) {
+        GPUMemoryPool_SetSampledIds(r->memorypool, IPCEnv_GetIds(env, r->local_dev_id, i), i);
+        GPUMemoryPool_SetLabels(r->memorypool, IPCEnv_GetLabels(env, r->local_dev_id, i), i);
+        GPUMemoryPool_SetAggSrcOf(r->memorypool, IPCEnv_GetAggSrc(env, r->local_dev_id, i), i);
+        GPUMemoryPool_SetAggDstOf(r->memorypool, IPCEnv_GetAggDst(env, r->local_dev_id, i), i);
+        GPUMemoryPool_SetNodeCounter(r->memorypool, IPCEnv_GetNodeCounter(env, r->local_dev_id, i), i);
+        GPUMemoryPool_SetEdgeCounter(r->memorypool, IPCEnv_GetEdgeCounter(env, r->local_dev_id, i), i);
+    }
+    r->events.resize(r->op_num);
+    r->op_params.resize(r->op_num);
+    for (int i = 0; i < r->op_num; i++) {
+        OpParams* op = new OpParams();
+        op->device_id = r->local_dev_id;
+        op->stream = r->streams[i % 2];
+        HIP_CHECK(hipEventCreateWithFlags(&r->events[i], hipEventDisableTiming));
+        op->event = r->events[i];
+        op->memorypool = r->memorypool;
+        op->cache = cache;
+        op->graph = params->graph;
+        op->noder = noder;
+        op->env = env;
+        op->neighbor_count = 0;
+        op->is_presc = 0;
+        op->in_memory = params->in_memory;
+        r->op_params[i] = op;
+    }
+    for (int i = 0; i < hop_num; i++) r->op_params[2 * i + 2]->neighbor_count = params->fanout[i];
+}
+
+// InitializeFeaturesBuffer, Server.cu:273-282: 1.2 x the largest batch seen while pre-sampling.
+// Clamped to the static bound; the gather never writes beyond the buffer (rows are clamped).
+void Runner_InitializeFeaturesBuffer(Runner* r, RunnerParams* params)
+{
+    GPUCache* cache = (GPUCache*)params->cache;
+    IPCEnv* env = (IPCEnv*)params->env;
+    DeviceGuard guard(r->local_dev_id);
+    HIP_CHECK(hipStreamSynchronize(r->streams[0]));
+    int64_t num_ids = (int64_t)(GPUCache_MaxIdNum(cache, r->local_dev_id) * 1.2);
+    if (num_ids > r->num_ids) num_ids = r->num_ids;
+    if (num_ids < 1) num_ids = r->num_ids;
+    r->feature_rows = (int32_t)num_ids;
+    IPCEnv_InitializeFeaturesBuffer(env, 0, (int32_t)num_ids, r->float_attr_len, r->local_dev_id, r->pipeline_depth);
+    for (int i = 0; i < r->pipeline_depth; i++)
+        GPUMemoryPool_SetFloatFeatures(r->memorypool, IPCEnv_GetFloatFeatures(env, r->local_dev_id, i), i);
+    GPUMemoryPool_SetFeatureRows(r->memorypool, (int32_t)num_ids);
+}
+
+// RunPreSc, Server.cu:284-299: only the even ops (BatchGen, samplers, planner), train mode
+void Runner_RunPreSc(Runner* r, RunnerParams* params)
+{
+    DeviceGuard guard(r->local_dev_id);
+    GPUMemoryPool_SetCurrentMode(r->memorypool, 0);
+    GPUMemoryPool_SetIter(r->memorypool, params->global_batch_id);
+    for (int i = 0; i < r->op_num; i += 2) {
+        r->op_params[i]->is_presc = 1;
+        Operator_run(r->op_factory[i], r->op_params[i]);
+    }
+    // the reference polls the (never recorded) updater event here, i.e. does not wait: batches of
+    // the pre-sampling epoch are simply queued in order on stream 0.
+}
+
+// RunOnce, Server.cu:301-328
+void Runner_RunOnce(Runner* r, RunnerParams* params)
+{
+    DeviceGuard guard(r->local_dev_id);
+    IPCEnv* env = (IPCEnv*)params->env;
+    const int32_t batch_id = params->global_batch_id;
+    r->mode = IPCEnv_GetCurrentMode(env, batch_id);
+    GPUMemoryPool_SetCurrentMode(r->memorypool, r->mode);
+    GPUMemoryPool_SetIter(r->memorypool, IPCEnv_GetLocalBatchId(env, batch_id));
+    IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
+    for (int i = 0; i < r->op_num; i++) {
+        if (i % 2 == 1) HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[i - 1], 0));
+        r->op_params[i]->is_presc = 0;
+        Operator_run(r->op_factory[i], r->op_params[i]);
+    }
+    HIP_CHECK(hipEventSynchronize(r->events[r->op_num - 1])); // reference: spin on cudaEventQuery
+    IPCEnv_IPCPost(env, r->local_dev_id, r->current_pipe);
+    r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
+    GPUMemoryPool_SetCurrentPipe(r->memorypool, r->current_pipe);
+}
+
+// Finalize, Server.cu:330-335
+void Runner_Finalize(Runner* r, RunnerParams* params)
+{
+    IPCEnv* env = (IPCEnv*)params->env;
+    IPCEnv_IPCWait(env, r->local_dev_id, (r->current_pipe + 1) % r->pipeline_depth);
+    DeviceGuard guard(r->local_dev_id);
+    GPUMemoryPool_Finalize(r->memorypool);
+}
+
+GPUMemoryPool* Runner_GetMemoryPool(Runner* r) { return r ? r->memorypool : nullptr; }
+
+void Runner_Delete(Runner* r)
+{
+    if (!r) return;
+    for (auto op : r->op_factory) Operator_Delete(op);
+    for (auto p : r->op_params) delete p;
+    for (auto e : r->events) (void)hipEventDestroy(e);
+    if (r->streams[0]) (void)hipStreamDestroy(r->streams[0]);
+    if (r->streams[1]) (void)hipStreamDestroy(r->streams[1]);
+    GPUMemoryPool_Delete(r->memorypool);
+    delete r;
+}
+
+} // extern "C"
+
+// =========================================== Server ======================================================
+namespace {
+
+// raw little-endian file -> memory (the mmap_*_read family, GPUGraphStore.cu:30-143)
+bool read_file(const std::string& path, void* dst, int64_t max_bytes, int64_t* got = nullptr, bool quiet = false)
+{
+    int fd = open(path.c_str(), O_RDONLY);
+    if (fd == -1) {
+        if (!quiet) std::cout << "cannout open file: " << path << "\n";
+        return false;
+    }
+    struct stat st;
+    fstat(fd, &st);
+    int64_t len = std::min<int64_t>(st.st_size, max_bytes);
+    const void* buf = mmap(nullptr, (size_t)(len > 0 ? len : 1), PROT_READ, MAP_PRIVATE, fd, 0);
+    if (buf == MAP_FAILED) { close(fd); return false; }
+    memcpy(dst, buf, (size_t)len);
+    munmap((void*)buf, (size_t)(len > 0 ? len : 1));
+    close(fd);
+    if (got) *got = len;
+    return true;
+}
+
+struct Meta { // ReadMetaFIle, GPUGraphStore.cu:190-223
+    std::string dataset_path;
+    int32_t raw_batch_size = 0, node_num = 0, float_attr_len = 0, training_set_num = 0, validation_set_num = 0,
+            testing_set_num = 0, epoch = 0, partition = 0;
+    int64_t edge_num = 0, cache_memory = 0;
+};
+
+} // namespace
+
+struct Server {
+    int shard_count = 0, train_step = 0, max_step = 0;
+    std::string meta_path = "./meta_config";
+    std::vector<int32_t> fanout{25, 10}; // Server.cu:68-69
+    Meta meta;
+    GPUGraphStorage* graph = nullptr;
+    GPUNodeStorage* noder = nullptr;
+    GPUCache* cache = nullptr;
+    IPCEnv* env = nullptr;
+    std::vector<Runner*> runners;
+    std::vector<RunnerParams*> params;
+    // host copies kept alive for Build()
+    std::vector<std::vector<int32_t>> tr_ids, va_ids, te_ids, tr_lab, va_lab, te_lab;
+    int64_t* indptr = nullptr;
+    int32_t* indices = nullptr;
+    float* feats = nullptr;
+};
+
+extern "C" {
+
+Server* NewGPUServer(void) { return new Server(); }
+void Server_SetFanout(Server* s, const int32_t* fanout, int32_t hops)
+{
+    if (!s || !fanout || hops < 1 || hops > LEGION_MAX_HOPS) { LEGION_ARG_ERROR("Server_SetFanout: bad arguments"); return; }
+    s->fanout.assign(fanout, fanout + hops);
+}
+void Server_SetMetaConfigPath(Server* s, const char* path) { if (s && path) s->meta_path = path; }
+
+// GPUServer::Initialize (Server.cu:45-81) + GPUGraphStore::Initialze (GPUGraphStore.cu:429-470)
+void Server_Initialize(Server* s, int global_shard_count)
+{
+    if (!s || global_shard_count < 1 || global_shard_count > kMaxParts) { LEGION_ARG_ERROR("Server_Initialize: shard count must be 1..8"); return; }
+    const int G = global_shard_count;
+    s->shard_count = G;
+    std::cout << "HIP Device Count: " << G << "\n";
+    Meta& m = s->meta;
+    {
+        std::ifstream f(s->meta_path);
+        if (!f.is_open()) { std::cout << "unable to open meta config file\n"; LEGION_ARG_ERROR("Server_Initialize: meta_config missing"); return; }
+        std::string line;
+        getline(f, line);
+        std::istringstream iss(line);
+        iss >> m.dataset_path >> m.raw_batch_size >> m.node_num >> m.edge_num >> m.float_attr_len >> m.training_set_num >>
+            m.validation_set_num >> m.testing_set_num >> m.cache_memory >> m.epoch >> m.partition;
+        std::cout << "Dataset path:       " << m.dataset_path << "\nRaw Batchsize:      " << m.raw_batch_size
+                  << "\nGraph nodes num:    " << m.node_num << "\nGraph edges num:    " << m.edge_num
+                  << "\nFeature dim:        " << m.float_attr_len << "\nTraining set num:   " << m.training_set_num
+                  << "\nValidation set num: " << m.validation_set_num << "\nTesting set num:    " << m.testing_set_num
+                  << "\nCache memory:       " << m.cache_memory << "\nTrain epoch:        " << m.epoch
+                  << "\nPartition?:         " << m.partition << "\n";
+    }
+    const int32_t V = m.node_num;
+    const int32_t F = m.float_attr_len;
+    // Load_Graph / Load_Feature (GPUGraphStore.cu:254-325): pinned, device-mapped host memory
+    std::cout << "Start load graph\n";
+    s->indptr = (int64_t*)host_alloc_space64(((int64_t)V + 1) * 8);
+    s->indices = (int32_t*)host_alloc_space64(m.edge_num * 4);
+    read_file(m.dataset_path + "edge_src", s->indptr, ((int64_t)V + 1) * 8);
+    read_file(m.dataset_path + "edge_dst", s->indices, m.edge_num * 4);
+    std::cout << "start load node\n";
+    s->feats = (float*)host_alloc_space64((int64_t)V * F * 4);
+    read_file(m.dataset_path + "features", s->feats, (int64_t)V * F * 4);
+    std::vector<int32_t> training_ids(m.training_set_num), validation_ids(m.validation_set_num), testing_ids(m.testing_set_num),
+        all_labels(V), partition_index(V);
+    read_file(m.dataset_path + "trainingset", training_ids.data(), (int64_t)m.training_set_num * 4);
+    read_file(m.dataset_path + "validationset", validation_ids.data(), (int64_t)m.validation_set_num * 4);
+    read_file(m.dataset_path + "testingset", testing_ids.data(), (int64_t)m.testing_set_num * 4);
+    read_file(m.dataset_path + "labels", all_labels.data(), (int64_t)V * 4);
+    const bool have_part = read_file(m.dataset_path + "partition_" + std::to_string(G) + "_bn", partition_index.data(), (int64_t)V * 4, nullptr, true);
+    std::cout << "Finish Reading All Files\n";
+    // seed split, GPUGraphStore.cu:332-414
+    s->tr_ids.assign(G, {}); s->va_ids.assign(G, {}); s->te_ids.assign(G, {});
+    s->tr_lab.assign(G, {}); s->va_lab.assign(G, {}); s->te_lab.assign(G, {});
+    for (int32_t tid : training_ids) {
+        int32_t part = (have_part && m.partition == 1) ? partition_index[tid] : tid % G;
+        if (part < G) s->tr_ids[part].push_back(tid);
+    }
+    for (int32_t tid : validation_ids) { int32_t part = tid % G; if (part < G) s->va_ids[part].push_back(tid); }
+    for (int32_t tid : testing_ids) { int32_t part = tid % G; if (part < G) s->te_ids[part].push_back(tid); }
+    std::vector<int32_t> tn(G), vn(G), en(G);
+    std::vector<const int32_t*> tp(G), vp(G), ep(G), tlp(G), vlp(G), elp(G);
+    for (int p = 0; p < G; p++) {
+        for (int32_t id : s->tr_ids[p]) s->tr_lab[p].push_back(all_labels[id]);
+        for (int32_t id : s->va_ids[p]) s->va_lab[p].push_back(all_labels[id]);
+        for (int32_t id : s->te_ids[p]) s->te_lab[p].push_back(all_labels[id]);
+        tn[p] = (int32_t)s->tr_ids[p].size(); vn[p] = (int32_t)s->va_ids[p].size(); en[p] = (int32_t)s->te_ids[p].size();
+        tp[p] = s->tr_ids[p].data(); vp[p] = s->va_ids[p].data(); ep[p] = s->te_ids[p].data();
+        tlp[p] = s->tr_lab[p].data(); vlp[p] = s->va_lab[p].data(); elp[p] = s->te_lab[p].data();
+    }
+    std::cout << "Finish Partition\n";
+    LegionBuildInfo info;
+    memset(&info, 0, sizeof(info));
+    info.partition_count = G;
+    info.training_set_num = tn.data(); info.training_set_ids = tp.data(); info.training_labels = tlp.data();
+    info.validation_set_num = vn.data(); info.validation_set_ids = vp.data(); info.validation_labels = vlp.data();
+    info.testing_set_num = en.data(); info.testing_set_ids = ep.data(); info.testing_labels = elp.data();
+    info.total_num_nodes = V; info.float_attr_len = F;
+    info.host_float_attrs = s->feats; info.features_location = LEGION_LOC_HOST_PINNED;
+    info.csr_node_index = s->indptr; info.csr_dst_node_ids = s->indices; info.csr_location = LEGION_LOC_HOST_PINNED;
+    info.total_edge_num = m.edge_num; info.cache_edge_num = 0;
+    info.epoch = m.epoch; info.raw_batch_size = m.raw_batch_size;
+
+    s->env = NewIPCEnv(G);
+    IPCEnv_Coordinate(s->env, &info);
+    s->noder = NewGPUMemoryNodeStorage();
+    GPUNodeStorage_Build(s->noder, &info);
+    s->graph = NewGPUMemoryGraphStorage();
+    GPUGraphStorage_Build(s->graph, &info);
+    s->cache = NewGPUCache();
+    const int32_t train_step = IPCEnv_GetTrainStep(s->env);
+    GPUCache_Initialize(s->cache, m.cache_memory, 0, F, train_step, G);
+    std::cout << "Storage Initialized\n";
+    s->train_step = train_step;
+    s->max_step = IPCEnv_GetMaxStep(s->env);
+    s->runners.resize(G);
+    s->params.resize(G);
+    for (int i = 0; i < G; i++) {
+        RunnerParams* p = new RunnerParams();
+        p->device_id = i;
+        p->fanout = s->fanout.data();
+        p->hops = (int32_t)s->fanout.size();
+        p->cache = s->cache; p->graph = s->graph; p->noder = s->noder; p->env = s->env;
+        p->global_batch_id = 0;
+        p->in_memory = 1;
+        s->params[i] = p;
+        s->runners[i] = NewGPURunner();
+        Runner_Initialize(s->runners[i], p);
+    }
+}
+
+// PreSc, Server.cu:83-114
+void Server_PreSc(Server* s, int cache_agg_mode)
+{
+    auto t1 = std::chrono::steady_clock::now();
+    std::vector<std::thread> pool;
+    for (int i = 0; i < s->shard_count; i++)
+        pool.emplace_back([s, i]() { // PreSCLoop, Server.cu:28-34
+            for (int b = 0; b < s->train_step; b++) {
+                s->params[i]->global_batch_id = b;
+                Runner_RunPreSc(s->runners[i], s->params[i]);
+            }
+            Runner_InitializeFeaturesBuffer(s->runners[i], s->params[i]);
+        });
+    for (auto& th : pool) th.join();
+    double t = std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t1).count();
+    GPUCache_CandidateSelection(s->cache, cache_agg_mode, s->noder, s->graph);
+    GPUCache_CostModel(s->cache, cache_agg_mode, s->noder, s->graph, nullptr, s->train_step);
+    GPUCache_FillUp(s->cache, cache_agg_mode, s->noder, s->graph);
+    std::cout << "First epoch cost: " << t << " s\n";
+    std::cout << "System is ready for serving\n" << std::flush;
+}
+
+// Run, Server.cu:116-135
+void Server_Run(Server* s)
+{
+    std::vector<std::thread> pool;
+    for (int i = 0; i < s->shard_count; i++)
+        pool.emplace_back([s, i]() { // RunnerLoop, Server.cu:36-41
+            for (int b = 0; b < s->max_step; b++) {
+                s->params[i]->global_batch_id = b;
+                Runner_RunOnce(s->runners[i], s->params[i]);
+            }
+        });
+    for (auto& th : pool) th.join();
+}
+
+// Finalize, Server.cu:137-146
+void Server_Finalize(Server* s)
+{
+    for (int i = 0; i < s->shard_count; i++) Runner_Finalize(s->runners[i], s->params[i]);
+    GPUGraphStorage_Finalize(s->graph);
+    GPUNodeStorage_Finalize(s->noder);
+    IPCEnv_Finalize(s->env);
+    std::cout << "Server Stopped\n";
+}
+
+void Server_Delete(Server* s)
+{
+    if (!s) return;
+    for (auto r : s->runners) Runner_Delete(r);
+    for (auto p : s->params) delete p;
+    if (s->cache) GPUCache_Delete(s->cache);
+    if (s->graph) GPUGraphStorage_Delete(s->graph);
+    if (s->noder) GPUNodeStorage_Delete(s->noder);
+    if (s->indptr) host_free_space(s->indptr);
+    if (s->indices) host_free_space(s->indices);
+    if (s->feats) host_free_space(s->feats);
+    delete s;
+}
+
+} // extern "C"

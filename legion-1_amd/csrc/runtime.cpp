@@ -1,0 +1,131 @@
+// runtime.cpp -- error handling, logical->physical device map and the raw device helpers
+// (reference: src/Kernels.cu:14-64, Kernels.cuh:14-45).
+#include "internal.h"
+
+#include <cstring>
+#include <mutex>
+
+namespace legion {
+
+static int g_error_mode = LEGION_ERR_EXIT;
+static thread_local std::string t_last_error;
+static int g_dev_map[64];
+static bool g_dev_map_set[64];
+static std::mutex g_mu;
+
+void report_error(const char* file, int line, const char* msg, bool hip_failure)
+{
+    char buf[1024];
+    // reference text: "Cuda failure %s:%d: '%s'" (Kernels.cuh:18)
+    snprintf(buf, sizeof(buf), "%s failure %s:%d: '%s'", hip_failure ? "Hip" : "Legion", file, line, msg);
+    if (hip_failure && g_error_mode == LEGION_ERR_EXIT) {
+        printf("%s\n", buf);
+        fflush(stdout);
+        exit(EXIT_FAILURE);
+    }
+    if (t_last_error.empty()) t_last_error = buf; // sticky: first error wins
+    if (!hip_failure && g_error_mode == LEGION_ERR_EXIT) fprintf(stderr, "%s\n", buf);
+    (void)hipGetLastError(); // clear HIP's own sticky flag so later calls are attributable
+}
+
+bool error_pending() { return !t_last_error.empty(); }
+
+int physical_device(int logical)
+{
+    if (logical >= 0 && logical < 64 && g_dev_map_set[logical]) return g_dev_map[logical];
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    return logical >= 0 ? logical % n : 0;
+}
+
+DeviceGuard::DeviceGuard(int logical)
+{
+    HIP_CHECK(hipGetDevice(&prev));
+    int want = physical_device(logical);
+    if (want != prev) HIP_CHECK(hipSetDevice(want));
+    else prev = -1;
+}
+DeviceGuard::~DeviceGuard()
+{
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+} // namespace legion
+
+using namespace legion;
+
+extern "C" {
+
+const char* legion_version(void) { return "legion-amd 0.1.0 (gfx950)"; }
+void legion_set_error_mode(int mode) { g_error_mode = mode; }
+const char* legion_last_error(void) { return t_last_error.c_str(); }
+void legion_clear_error(void) { t_last_error.clear(); }
+
+void legion_set_device_map(int32_t logical_dev, int32_t physical_dev)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (logical_dev < 0 || logical_dev >= 64) { LEGION_ARG_ERROR("legion_set_device_map: logical id out of range"); return; }
+    g_dev_map[logical_dev] = physical_dev;
+    g_dev_map_set[logical_dev] = true;
+}
+int32_t legion_physical_device(int32_t logical_dev) { return physical_device(logical_dev); }
+
+// ---- Kernels.cu:14-64 ---------------------------------------------------------------------------
+void* d_alloc_space(int64_t num_bytes)
+{
+    void* ret = nullptr;
+    HIP_CHECK(hipMalloc(&ret, (size_t)(num_bytes > 0 ? num_bytes : 1)));
+    return ret;
+}
+void* d_alloc_space_managed(unsigned int num_bytes)
+{
+    void* ret = nullptr;
+    HIP_CHECK(hipMallocManaged(&ret, num_bytes ? num_bytes : 1));
+    return ret;
+}
+void d_copy_2_h(void* h_ptr, void* d_ptr, unsigned int num_bytes)
+{
+    HIP_CHECK(hipMemcpy(h_ptr, d_ptr, num_bytes, hipMemcpyDeviceToHost));
+}
+void d_free_space(void* d_ptr) { (void)hipFree(d_ptr); }
+void SetGPUDevice(int32_t shard_id) { HIP_CHECK(hipSetDevice(physical_device(shard_id))); }
+int32_t GetGPUDevice(void)
+{
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    return dev;
+}
+void* host_alloc_space64(int64_t num_bytes)
+{
+    void* host_ptr = nullptr;
+    void* ret = nullptr;
+    HIP_CHECK(hipHostMalloc(&host_ptr, (size_t)(num_bytes > 0 ? num_bytes : 1), hipHostMallocMapped | hipHostMallocPortable));
+    if (!host_ptr) return nullptr;
+    HIP_CHECK(hipHostGetDevicePointer(&ret, host_ptr, 0));
+    return ret;
+}
+void* host_alloc_space(unsigned int num_bytes) { return host_alloc_space64((int64_t)num_bytes); }
+void host_free_space(void* ptr) { (void)hipHostFree(ptr); }
+void d_copy_h_2_d(void* d_ptr, const void* h_ptr, int64_t num_bytes)
+{
+    HIP_CHECK(hipMemcpy(d_ptr, h_ptr, (size_t)num_bytes, hipMemcpyHostToDevice));
+}
+void d_copy_d_2_h(void* h_ptr, const void* d_ptr, int64_t num_bytes)
+{
+    HIP_CHECK(hipMemcpy(h_ptr, d_ptr, (size_t)num_bytes, hipMemcpyDeviceToHost));
+}
+void d_stream_sync(void* stream) { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }
+void* d_stream_create(void)
+{
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return (void*)s;
+}
+void d_stream_destroy(void* stream) { (void)hipStreamDestroy((hipStream_t)stream); }
+
+void legion_rng_probe(void* stream, const int32_t* idx, const int32_t* deg, int32_t* k_out, int32_t n)
+{
+    launch_rng_probe((hipStream_t)stream, idx, deg, k_out, n);
+}
+
+} // extern "C"

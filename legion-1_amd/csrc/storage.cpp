@@ -1,0 +1,321 @@
+// storage.cpp -- host mirrors of GPUMemoryGraphStorage (GPU_Memory_Graph_Storage.cu:37-210),
+// GPUMemoryNodeStorage (GPU_Memory_Node_Storage.cu:3-207) and GPUMemoryPool (GPUMemoryPool.cuh:7-208).
+#include "internal.h"
+
+#include <cstring>
+#include <set>
+
+using namespace legion;
+
+// all-pairs peer access between the physical devices behind the logical GPUs
+// (GPUGraphStore::EnableP2PAccess, GPUGraphStore.cu:145-168)
+static void enable_p2p(int32_t partition_count)
+{
+    std::set<int> phys;
+    for (int i = 0; i < partition_count; i++) phys.insert(physical_device(i));
+    if (phys.size() < 2) return;
+    int cur = 0;
+    HIP_CHECK(hipGetDevice(&cur));
+    for (int a : phys) {
+        HIP_CHECK(hipSetDevice(a));
+        for (int b : phys) {
+            if (a == b) continue;
+            int ok = 0;
+            HIP_CHECK(hipDeviceCanAccessPeer(&ok, a, b));
+            if (ok) {
+                hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_CHECK(e);
+                (void)hipGetLastError();
+            }
+        }
+    }
+    HIP_CHECK(hipSetDevice(cur));
+}
+
+template <typename T>
+static T* adopt_table(const T* src, int64_t count, int32_t location, bool* owns)
+{
+    *owns = false;
+    if (location == LEGION_LOC_HOST_PAGEABLE) {
+        T* p = (T*)host_alloc_space64(count * (int64_t)sizeof(T));
+        if (p) memcpy(p, src, (size_t)count * sizeof(T));
+        *owns = true;
+        return p;
+    }
+    return const_cast<T*>(src);
+}
+
+extern "C" {
+
+// ================================= graph storage ====================================================
+GPUGraphStorage* NewGPUMemoryGraphStorage(void) { return new GPUGraphStorage(); }
+
+void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info)
+{
+    if (!g || !info) { LEGION_ARG_ERROR("GPUGraphStorage_Build: null argument"); return; }
+    if (info->partition_count < 1 || info->partition_count > kMaxParts) { LEGION_ARG_ERROR("GPUGraphStorage_Build: partition_count must be 1..8"); return; }
+    const int P = info->partition_count;
+    g->partition_count = P;
+    g->node_num = info->total_num_nodes;
+    g->edge_num = info->total_edge_num;
+    g->cache_edge_num = info->cache_edge_num;
+    g->csr_location = info->csr_location;
+    enable_p2p(P);
+    bool o1 = false, o2 = false;
+    g->csr_node_index_cpu = adopt_table<int64_t>(info->csr_node_index, (int64_t)info->total_num_nodes + 1, info->csr_location, &o1);
+    g->csr_dst_node_ids_cpu = adopt_table<int32_t>(info->csr_dst_node_ids, info->total_edge_num, info->csr_location, &o2);
+    g->owns_csr = o1 || o2;
+    if (o1) g->csr_location = LEGION_LOC_HOST_PINNED;
+    g->frag_indptr.assign(P, nullptr);
+    g->frag_indices.assign(P, nullptr);
+    g->frag_rows.assign(P, 0);
+    g->view_indptr.assign(P, std::vector<int64_t*>(P, nullptr));
+    g->view_indices.assign(P, std::vector<int32_t*>(P, nullptr));
+}
+
+// GraphCache (GPU_Memory_Graph_Storage.cu:98-133): fragment of clique GPU i holds rows QT[r*Kg+i]
+void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity)
+{
+    if (!g || !QT || Kg < 1 || (Ki + 1) * Kg > g->partition_count) { LEGION_ARG_ERROR("GraphCache: bad clique"); return; }
+    for (int i = 0; i < Kg; i++) {
+        const int dev = Ki * Kg + i;
+        DeviceGuard guard(dev);
+        if (g->frag_indptr[dev]) { (void)hipFree(g->frag_indptr[dev]); g->frag_indptr[dev] = nullptr; }
+        if (g->frag_indices[dev]) { (void)hipFree(g->frag_indices[dev]); g->frag_indices[dev] = nullptr; }
+        g->frag_rows[dev] = capacity;
+        if (capacity <= 0) continue;
+        int64_t* neighbor_count = nullptr;
+        int64_t* d_index = nullptr;
+        HIP_CHECK(hipMalloc(&neighbor_count, (size_t)capacity * sizeof(int64_t)));
+        HIP_CHECK(hipMalloc(&d_index, ((size_t)capacity + 1) * sizeof(int64_t)));
+        HIP_CHECK(hipMemset(d_index, 0, sizeof(int64_t)));
+        launch_neighbor_count(nullptr, QT, Kg, i, capacity, g->node_num, g->csr_node_index_cpu, neighbor_count);
+        inclusive_scan_i64(nullptr, neighbor_count, d_index + 1, capacity);
+        int64_t total = 0;
+        HIP_CHECK(hipMemcpy(&total, d_index + capacity, sizeof(int64_t), hipMemcpyDeviceToHost));
+        int32_t* d_ids = nullptr;
+        HIP_CHECK(hipMalloc(&d_ids, (size_t)(total > 0 ? total : 1) * sizeof(int32_t)));
+        launch_topo_fill_up(nullptr, QT, Kg, i, capacity, g->node_num, g->csr_node_index_cpu, g->csr_dst_node_ids_cpu, d_index, d_ids);
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipFree(neighbor_count));
+        g->frag_indptr[dev] = d_index;
+        g->frag_indices[dev] = d_ids;
+    }
+    // every clique member sees every clique fragment (pointer tables copied D2D in the reference, :128-131)
+    for (int i = 0; i < Kg; i++)
+        for (int j = 0; j < Kg; j++) {
+            g->view_indptr[Ki * Kg + i][Ki * Kg + j] = g->frag_indptr[Ki * Kg + j];
+            g->view_indices[Ki * Kg + i][Ki * Kg + j] = g->frag_indices[Ki * Kg + j];
+        }
+}
+
+void GPUGraphStorage_Finalize(GPUGraphStorage* g)
+{
+    if (!g) return;
+    for (size_t i = 0; i < g->frag_indptr.size(); i++) {
+        if (g->frag_indptr[i]) (void)hipFree(g->frag_indptr[i]);
+        if (g->frag_indices[i]) (void)hipFree(g->frag_indices[i]);
+        g->frag_indptr[i] = nullptr;
+        g->frag_indices[i] = nullptr;
+    }
+    if (g->owns_csr) {
+        host_free_space(g->csr_node_index_cpu);
+        host_free_space(g->csr_dst_node_ids_cpu);
+        g->owns_csr = false;
+    }
+}
+int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g) { return g->partition_count; }
+int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g) { return g->csr_node_index_cpu; }
+int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g) { return g->csr_dst_node_ids_cpu; }
+int64_t* GPUGraphStorage_GetFragmentIndex(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id)
+{
+    if (dev_id < 0 || dev_id >= g->partition_count || part_id < 0 || part_id >= g->partition_count) return nullptr;
+    return g->view_indptr[dev_id][part_id];
+}
+int32_t* GPUGraphStorage_GetFragmentMatrix(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id)
+{
+    if (dev_id < 0 || dev_id >= g->partition_count || part_id < 0 || part_id >= g->partition_count) return nullptr;
+    return g->view_indices[dev_id][part_id];
+}
+void GPUGraphStorage_Delete(GPUGraphStorage* g)
+{
+    if (!g) return;
+    GPUGraphStorage_Finalize(g);
+    delete g;
+}
+
+// ================================= node storage =====================================================
+GPUNodeStorage* NewGPUMemoryNodeStorage(void) { return new GPUNodeStorage(); }
+
+static int32_t* upload_i32(const int32_t* src, int32_t n)
+{
+    int32_t* d = nullptr;
+    HIP_CHECK(hipMalloc(&d, (size_t)(n > 0 ? n : 1) * sizeof(int32_t)));
+    if (n > 0 && src) HIP_CHECK(hipMemcpy(d, src, (size_t)n * sizeof(int32_t), hipMemcpyDefault));
+    return d;
+}
+
+void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
+{
+    if (!n || !info) { LEGION_ARG_ERROR("GPUNodeStorage_Build: null argument"); return; }
+    const int P = info->partition_count;
+    if (P < 1 || P > kMaxParts) { LEGION_ARG_ERROR("GPUNodeStorage_Build: partition_count must be 1..8"); return; }
+    n->partition_count = P;
+    n->total_num_nodes = info->total_num_nodes;
+    n->float_attr_len = info->float_attr_len;
+    n->features_location = info->features_location;
+    bool owns = false;
+    n->float_attrs = info->host_float_attrs
+        ? adopt_table<float>(info->host_float_attrs, (int64_t)info->total_num_nodes * info->float_attr_len, info->features_location, &owns)
+        : nullptr;
+    n->owns_features = owns;
+    n->training_set_num.assign(P, 0); n->validation_set_num.assign(P, 0); n->testing_set_num.assign(P, 0);
+    n->training_set_ids.assign(P, nullptr); n->validation_set_ids.assign(P, nullptr); n->testing_set_ids.assign(P, nullptr);
+    n->training_labels.assign(P, nullptr); n->validation_labels.assign(P, nullptr); n->testing_labels.assign(P, nullptr);
+    for (int p = 0; p < P; p++) { // GPU_Memory_Node_Storage.cu:41-96
+        DeviceGuard guard(p);
+        if (info->training_set_num) {
+            n->training_set_num[p] = info->training_set_num[p];
+            n->training_set_ids[p] = upload_i32(info->training_set_ids[p], info->training_set_num[p]);
+            n->training_labels[p] = upload_i32(info->training_labels[p], info->training_set_num[p]);
+        }
+        if (info->validation_set_num) {
+            n->validation_set_num[p] = info->validation_set_num[p];
+            n->validation_set_ids[p] = upload_i32(info->validation_set_ids[p], info->validation_set_num[p]);
+            n->validation_labels[p] = upload_i32(info->validation_labels[p], info->validation_set_num[p]);
+        }
+        if (info->testing_set_num) {
+            n->testing_set_num[p] = info->testing_set_num[p];
+            n->testing_set_ids[p] = upload_i32(info->testing_set_ids[p], info->testing_set_num[p]);
+            n->testing_labels[p] = upload_i32(info->testing_labels[p], info->testing_set_num[p]);
+        }
+    }
+}
+
+void GPUNodeStorage_Finalize(GPUNodeStorage* n)
+{
+    if (!n) return;
+    auto drop = [](std::vector<int32_t*>& v) { for (auto& p : v) { if (p) (void)hipFree(p); p = nullptr; } };
+    drop(n->training_set_ids); drop(n->validation_set_ids); drop(n->testing_set_ids);
+    drop(n->training_labels); drop(n->validation_labels); drop(n->testing_labels);
+    if (n->owns_features) { host_free_space(n->float_attrs); n->owns_features = false; }
+}
+#define NS_GETTER(name, field) \
+    int32_t* GPUNodeStorage_##name(const GPUNodeStorage* n, int32_t part_id) { \
+        return (part_id >= 0 && part_id < n->partition_count) ? n->field[part_id] : nullptr; }
+NS_GETTER(GetTrainingSetIds, training_set_ids)
+NS_GETTER(GetValidationSetIds, validation_set_ids)
+NS_GETTER(GetTestingSetIds, testing_set_ids)
+NS_GETTER(GetTrainingLabels, training_labels)
+NS_GETTER(GetValidationLabels, validation_labels)
+NS_GETTER(GetTestingLabels, testing_labels)
+#undef NS_GETTER
+int32_t GPUNodeStorage_TrainingSetSize(const GPUNodeStorage* n, int32_t p) { return (p >= 0 && p < n->partition_count) ? n->training_set_num[p] : 0; }
+int32_t GPUNodeStorage_ValidationSetSize(const GPUNodeStorage* n, int32_t p) { return (p >= 0 && p < n->partition_count) ? n->validation_set_num[p] : 0; }
+int32_t GPUNodeStorage_TestingSetSize(const GPUNodeStorage* n, int32_t p) { return (p >= 0 && p < n->partition_count) ? n->testing_set_num[p] : 0; }
+int32_t GPUNodeStorage_TotalNodeNum(const GPUNodeStorage* n) { return n->total_num_nodes; }
+float* GPUNodeStorage_GetAllFloatAttr(const GPUNodeStorage* n) { return n->float_attrs; }
+int32_t GPUNodeStorage_GetFloatAttrLen(const GPUNodeStorage* n) { return n->float_attr_len; }
+void GPUNodeStorage_Delete(GPUNodeStorage* n)
+{
+    if (!n) return;
+    GPUNodeStorage_Finalize(n);
+    delete n;
+}
+
+} // extern "C"
+
+// ================================= memory pool ======================================================
+GPUMemoryPool::GPUMemoryPool(int32_t depth)
+{
+    pipeline_depth = depth > 0 ? depth : 1;
+    float_features.assign(pipeline_depth, nullptr);
+    labels.assign(pipeline_depth, nullptr);
+    node_counter.assign(pipeline_depth, nullptr);
+    edge_counter.assign(pipeline_depth, nullptr);
+    sampled_ids.assign(pipeline_depth, nullptr);
+    agg_src_off.assign(pipeline_depth, nullptr);
+    agg_dst_off.assign(pipeline_depth, nullptr);
+}
+
+extern "C" {
+
+GPUMemoryPool* NewGPUMemoryPool(int32_t pipeline_depth) { return new GPUMemoryPool(pipeline_depth); }
+
+// Server.cu:184-196 (num_ids_) and :216-231 (scratch), sized for H hops
+void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, int32_t batch_size,
+                                   const int32_t* fanout, int32_t hops)
+{
+    if (!p || hops < 1 || hops > LEGION_MAX_HOPS || batch_size < 1 || total_num_nodes < 1) { LEGION_ARG_ERROR("GPUMemoryPool_AllocateScratch: bad arguments"); return; }
+    p->V = total_num_nodes; p->batch_size = batch_size; p->hops = hops;
+    int64_t ids = batch_size, cur = batch_size, max_slots = 0;
+    p->level_bound[0] = batch_size;
+    for (int h = 0; h < hops; h++) {
+        p->fanout[h] = fanout[h];
+        cur *= fanout[h];
+        if (cur > max_slots) max_slots = cur;
+        ids += cur;
+        if (ids >= (1ll << 31)) { LEGION_ARG_ERROR("GPUMemoryPool_AllocateScratch: batch*fanouts exceeds int32"); return; }
+        p->level_bound[h + 1] = (int32_t)cur;
+    }
+    p->num_ids = (int32_t)ids;
+    p->max_slots = (int32_t)max_slots;
+    p->max_tiles = (int32_t)((max_slots + kTile - 1) / kTile);
+    p->owns_scratch = true;
+    HIP_CHECK(hipMalloc(&p->pos_map, (size_t)total_num_nodes * sizeof(uint32_t)));
+    HIP_CHECK(hipMemset(p->pos_map, 0xFF, (size_t)total_num_nodes * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&p->cand, (size_t)p->max_slots * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&p->tile_edge, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&p->tile_node, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&p->hop_state, sizeof(HopState)));
+    HIP_CHECK(hipMalloc(&p->cache_search_buffer, (size_t)p->num_ids * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&p->agg_src_ids, (size_t)p->num_ids * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&p->tmp_part_ind, (size_t)p->num_ids));
+    HIP_CHECK(hipMalloc(&p->tmp_part_off, (size_t)p->num_ids * sizeof(int32_t)));
+    HIP_CHECK(hipDeviceSynchronize());
+}
+int32_t GPUMemoryPool_NumIds(const GPUMemoryPool* p) { return p->num_ids; }
+
+#define POOL_PIPE_SETTER(name, field, type) \
+    void GPUMemoryPool_Set##name(GPUMemoryPool* p, type* ptr, int32_t pipe) { \
+        if (pipe < 0 || pipe >= p->pipeline_depth) { LEGION_ARG_ERROR("GPUMemoryPool_Set" #name ": bad pipe"); return; } \
+        p->field[pipe] = ptr; } \
+    type* GPUMemoryPool_Get##name(const GPUMemoryPool* p) { return p->field[p->current_pipe]; }
+POOL_PIPE_SETTER(SampledIds, sampled_ids, int32_t)
+POOL_PIPE_SETTER(FloatFeatures, float_features, float)
+POOL_PIPE_SETTER(Labels, labels, int32_t)
+POOL_PIPE_SETTER(AggSrcOf, agg_src_off, int32_t)
+POOL_PIPE_SETTER(AggDstOf, agg_dst_off, int32_t)
+POOL_PIPE_SETTER(NodeCounter, node_counter, int32_t)
+POOL_PIPE_SETTER(EdgeCounter, edge_counter, int32_t)
+#undef POOL_PIPE_SETTER
+void GPUMemoryPool_SetFeatureRows(GPUMemoryPool* p, int32_t rows) { p->feature_rows = rows; }
+void GPUMemoryPool_SetCurrentPipe(GPUMemoryPool* p, int32_t pipe) { p->current_pipe = pipe % p->pipeline_depth; }
+void GPUMemoryPool_SetCurrentMode(GPUMemoryPool* p, int32_t mode) { p->mode = mode; }
+void GPUMemoryPool_SetIter(GPUMemoryPool* p, int32_t iter) { p->iter = iter; }
+int32_t GPUMemoryPool_GetCurrentMode(const GPUMemoryPool* p) { return p->mode; }
+int32_t GPUMemoryPool_GetIter(const GPUMemoryPool* p) { return p->iter; }
+int32_t* GPUMemoryPool_GetAggSrcId(const GPUMemoryPool* p) { return p->agg_src_ids; }
+int32_t* GPUMemoryPool_GetCacheSearchBuffer(const GPUMemoryPool* p) { return p->cache_search_buffer; }
+char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p) { return (char*)p->tmp_part_ind; }
+int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p) { return p->tmp_part_off; }
+uint32_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p) { return p->pos_map; }
+
+void GPUMemoryPool_Finalize(GPUMemoryPool* p)
+{
+    if (!p || !p->owns_scratch) return;
+    (void)hipFree(p->pos_map); (void)hipFree(p->cand); (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
+    (void)hipFree(p->hop_state); (void)hipFree(p->cache_search_buffer); (void)hipFree(p->agg_src_ids);
+    (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off);
+    p->pos_map = nullptr; p->cand = nullptr; p->tile_edge = p->tile_node = nullptr; p->hop_state = nullptr;
+    p->cache_search_buffer = p->agg_src_ids = p->tmp_part_off = nullptr; p->tmp_part_ind = nullptr;
+    p->owns_scratch = false;
+}
+void GPUMemoryPool_Delete(GPUMemoryPool* p)
+{
+    if (!p) return;
+    GPUMemoryPool_Finalize(p);
+    delete p;
+}
+
+} // extern "C"

@@ -1,0 +1,135 @@
+// synth.hip -- on-GPU generator of the synthetic datasets specified in legion-1_amd/synth.py
+// (same closed forms, integer only, so host/numpy and device outputs are bit identical), and
+// the streaming copy used by bench.py to report the measured HBM peak.
+#include "internal.h"
+
+namespace legion {
+
+__host__ __device__ inline uint64_t sm64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+constexpr uint64_t GEN_SEED = 0x1E610ull;
+constexpr uint64_t S_DEG = (GEN_SEED << 32) ^ 0x0DE6ull;
+constexpr uint64_t S_NBR = (GEN_SEED << 32) ^ 0x0EB2ull;
+constexpr uint64_t S_FEAT = (GEN_SEED << 32) ^ 0xFEA7ull;
+constexpr uint64_t S_LAB = (GEN_SEED << 32) ^ 0x1AB1ull;
+constexpr int NBUCKET = 24;
+
+struct Ladder { int32_t lo[NBUCKET + 2]; };
+
+__global__ void k_synth_degrees(int64_t* out, int32_t v0, int32_t n, Ladder lad)
+{
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t h = sm64(S_DEG + (uint64_t)(v0 + i));
+        const uint32_t top = (uint32_t)(h >> 40);
+        const int b = top ? (__clz(top) - 8) : NBUCKET;
+        const int64_t lo = lad.lo[b], span = (int64_t)lad.lo[b + 1] - lo;
+        out[i] = lo + (int64_t)((h & 0xFFFFFFFFull) % (uint64_t)span);
+    }
+}
+
+__global__ void k_synth_neighbors(int32_t* out, int64_t e0, int64_t n, uint32_t V, uint32_t M, uint32_t C)
+{
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = sm64(S_NBR + (uint64_t)(e0 + i));
+        const uint64_t a = h >> 32;
+        uint64_t x = a;
+        if ((h & 0xFF) < 205) x = (((a * a) >> 32) * a) >> 32;
+        const uint64_t r = (x * (uint64_t)V) >> 32;
+        out[i] = (int32_t)((r * (uint64_t)M + (uint64_t)C) % (uint64_t)V);
+    }
+}
+
+__global__ void k_synth_features(float* out, int64_t v0, int64_t nrows, int32_t F)
+{
+    const int64_t n = nrows * F;
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t h = sm64(S_FEAT + (uint64_t)(v0 * F + i));
+        out[i] = (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f - 0.5f; // 2^-24
+    }
+}
+
+__global__ void k_synth_labels(int32_t* out, int32_t v0, int32_t n, int32_t classes)
+{
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x)
+        out[i] = (int32_t)(sm64(S_LAB + (uint64_t)(v0 + i)) % (uint64_t)classes);
+}
+
+// out[k] = (i*M2 + C2) % V for i = i0 + phase + k*stride  (stride/phase: the tid % G split of a
+// permutation-ordered seed list cannot be written in closed form, so the split is done by the
+// caller; stride = 1, phase = 0 yields the plain list)
+__global__ void k_synth_seed_ids(int32_t* out, int64_t i0, int64_t n, uint32_t V, uint32_t M2, uint32_t C2,
+                                 int32_t stride, int32_t phase)
+{
+    for (int64_t k = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = (uint64_t)(i0 + phase + k * stride);
+        out[k] = (int32_t)((i * (uint64_t)M2 + (uint64_t)C2) % (uint64_t)V);
+    }
+}
+
+__global__ void k_copy_f4(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n)
+{
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+} // namespace legion
+
+using namespace legion;
+
+static inline int big_grid(int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    if (b < 1) b = 1;
+    return (int)(b < 4096 ? b : 4096);
+}
+
+extern "C" {
+
+void legion_synth_degrees(void* stream, int64_t* deg_out, int32_t v0, int32_t n, const int32_t* ladder_host26)
+{
+    if (n <= 0) return;
+    Ladder lad;
+    for (int i = 0; i < NBUCKET + 2; i++) lad.lo[i] = ladder_host26[i];
+    k_synth_degrees<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(deg_out, v0, n, lad);
+    HIP_CHECK_LAST();
+}
+void legion_synth_neighbors(void* stream, int32_t* indices_out, int64_t e0, int64_t n, int32_t V, uint32_t M, uint32_t C)
+{
+    if (n <= 0) return;
+    k_synth_neighbors<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(indices_out, e0, n, (uint32_t)V, M, C);
+    HIP_CHECK_LAST();
+}
+void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F)
+{
+    if (nrows <= 0) return;
+    k_synth_features<<<big_grid(nrows * F), 256, 0, (hipStream_t)stream>>>(out, v0, nrows, F);
+    HIP_CHECK_LAST();
+}
+void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int32_t classes)
+{
+    if (n <= 0) return;
+    k_synth_labels<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(out, v0, n, classes);
+    HIP_CHECK_LAST();
+}
+void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, int32_t V, uint32_t M2, uint32_t C2,
+                           int32_t stride, int32_t phase)
+{
+    if (n <= 0) return;
+    k_synth_seed_ids<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(out, i0, n, (uint32_t)V, M2, C2, stride, phase);
+    HIP_CHECK_LAST();
+}
+void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes)
+{
+    const int64_t n = bytes / 16;
+    if (n <= 0) return;
+    k_copy_f4<<<2048, 256, 0, (hipStream_t)stream>>>((float4*)dst, (const float4*)src, n);
+    HIP_CHECK_LAST();
+}
+
+} // extern "C"

@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the mini-batch hot path (sampler + compaction + feature gather) on a
+synthetic graph of the ogbn-papers100M shape (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one mini-batch (B seeds, H-hop sampling, COO construction, gather of every unique
+node's feature row) with CSR and features already resident in HBM.  Each rank owns the seeds
+`tid % N == rank` (GPUGraphStore.cu:332-346) and a full replica of the graph (Kg = 1), so there is
+no data-path collective: scaling is weak.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="papers100M", choices=["products", "papers100M", "uk-union"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink V and seed sets (debug only)")
+    ap.add_argument("--batch", type=int, default=8000)
+    ap.add_argument("--fanout", default="25,10,5")
+    ap.add_argument("--gather", default="all", choices=["all", "level"], help="one gather per batch or one per level")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
+    return ap.parse_args()
+
+
+def build_graph_on_gpu(K, spec, dev):
+    """Synthetic dataset generated on the GPU by csrc/synth.hip (spec: legion-1_amd/synth.py)."""
+    L = K.lib()
+    V, F = spec.V, spec.F
+    ladder = np.ascontiguousarray(spec.ladder, dtype=np.int32)
+    deg = torch.empty(V, dtype=torch.int64, device=dev)
+    L.legion_synth_degrees(None, deg.data_ptr(), 0, V, ladder.ctypes.data)
+    indptr = torch.zeros(V + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg, 0, out=indptr[1:])
+    del deg
+    E = int(indptr[-1].item())
+    indices = torch.empty(E, dtype=torch.int32, device=dev)
+    L.legion_synth_neighbors(None, indices.data_ptr(), 0, E, V, spec.M, spec.C)
+    feats = torch.empty((V, F), dtype=torch.float32, device=dev)
+    L.legion_synth_features(None, feats.data_ptr(), 0, V, F)
+    torch.cuda.synchronize()
+    K.check()
+    return indptr, indices, feats, E
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import legion1_amd.capi as K
+    import legion1_amd.synth as S
+    L = K.lib()
+    L.legion_set_device_map(0, local_rank)  # this process drives one logical GPU (dev 0 of a 1-partition world)
+    L.SetGPUDevice(0)
+
+    fan = [int(x) for x in args.fanout.split(",")]
+    H = len(fan)
+    B = args.batch
+    spec = S.spec_for(args.workload, scale=args.scale)
+    V, F = spec.V, spec.F
+    t0 = time.time()
+    indptr, indices, feats, E = build_graph_on_gpu(K, spec, dev)
+    # seeds of this rank: train ids with tid % world == rank, labels from the generator
+    all_train = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
+    L.legion_synth_seed_ids(None, all_train.data_ptr(), 0, spec.n_train, V, spec.M2, spec.C2, 1, 0)
+    torch.cuda.synchronize()
+    mine = all_train[(all_train % world) == rank].contiguous()
+    del all_train
+    labels_all = torch.empty(V, dtype=torch.int32, device=dev)
+    L.legion_synth_labels(None, labels_all.data_ptr(), 0, V, spec.classes)
+    torch.cuda.synchronize()
+    my_labels = labels_all[mine.long()].contiguous()
+    del labels_all
+    n_mine = int(mine.numel())
+    gen_s = time.time() - t0
+
+    seeds = dict(train=[((mine.data_ptr(), n_mine), (my_labels.data_ptr(), n_mine))])
+    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=1,
+                   csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E)
+    eng.alloc_features()
+    stream = L.d_stream_create()
+    steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
+    K_steps, W = args.steps, args.warmup
+
+    per_level = args.gather == "level"
+    log = K.DevBuf((K_steps + W) * 128)  # nc/ec of every step, copied on-stream
+    ev = [(L.d_event_create(), L.d_event_create()) for _ in range(K_steps)]
+    pool = eng.pools[0]
+    o = eng.out[0][0]
+
+    def step(i, timed_idx=None):
+        it = i % steps_avail
+        L.GPUMemoryPool_SetCurrentPipe(pool, 0)
+        L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, it, 0, 0, K.TRAINMODE)
+        if per_level:
+            L.get_feature_kernel(stream, eng.cache, eng.noder, pool, 0, 1, 1)
+        for h in range(H):
+            L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
+            if per_level:
+                L.get_feature_kernel(stream, eng.cache, eng.noder, pool, 0, 2 * h + 3, 1)
+        if not per_level:
+            if timed_idx is not None:
+                L.d_event_record(ev[timed_idx][0], stream)
+            L.get_feature_kernel_all(stream, eng.cache, eng.noder, pool, 0, 1)
+            if timed_idx is not None:
+                L.d_event_record(ev[timed_idx][1], stream)
+        L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
+        L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
+        L.make_update_plan(stream, eng.graph, eng.cache, pool, 0, K.TRAINMODE)
+        L.update_cache(stream, eng.cache, eng.noder, pool, 0, K.TRAINMODE)
+
+    def barrier():
+        L.d_stream_sync(stream)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(W):
+        step(i)
+    barrier()
+    t_start = time.perf_counter()
+    for i in range(K_steps):
+        step(W + i, timed_idx=i)
+    L.d_stream_sync(stream)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        torch.distributed.barrier()
+    K.check()
+
+    counters = log.to_numpy(np.int32, (K_steps + W) * 32).reshape(K_steps + W, 2, 16)[W:]
+    edges = counters[:, 1, 2 + H].astype(np.int64)          # ec[2+H]: cumulative edges of the batch
+    nodes = counters[:, 0, 5 + 2 * H].astype(np.int64)      # nc[5+2H]: unique nodes (rows gathered)
+    cum = [np.zeros(K_steps, dtype=np.int64)] + [counters[:, 1, 2 + h].astype(np.int64) for h in range(1, H + 1)]
+    e_h = [cum[h] - cum[h - 1] for h in range(1, H + 1)]                       # edges sampled in hop h
+    n_in = [counters[:, 0, 4].astype(np.int64)] + e_h[:-1]                     # input slots of hop h
+    u_h = [counters[:, 0, 4 + 2 * h].astype(np.int64) for h in range(1, H + 1)]  # new unique nodes of hop h
+    # algorithmic bytes: sampler 20*N_h + 28*E_h + 8*U_h per hop, gather (8F+8) per row
+    samp_bytes = sum(20 * n_in[h] + 28 * e_h[h] + 8 * u_h[h] for h in range(H))
+    gather_bytes = nodes * (8 * F + 8)
+    tot_edges, tot_nodes = int(edges.sum()), int(nodes.sum())
+
+    stats = torch.tensor([elapsed, float(tot_edges), float(tot_nodes), float(samp_bytes.sum() + gather_bytes.sum())],
+                         dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
+        elapsed_max = float(mx[0].item())
+    else:
+        elapsed_max = elapsed
+    job_edges, job_nodes, job_bytes = float(stats[1].item()), float(stats[2].item()), float(stats[3].item())
+
+    # dominant kernel (k_gather: it moves ~90 % of the batch's algorithmic bytes), HIP events on our stream
+    roofline = None
+    if not per_level:
+        g_ms = np.array([L.d_event_elapsed_ms(a, b) for a, b in ev], dtype=np.float64)
+        ach = float(gather_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel="k_gather<float4,4>", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                        frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
+                        avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),
+                        algorithmic_bytes_per_launch=int(gather_bytes.mean()),
+                        pipeline_frac=round(job_bytes / elapsed_max / 1e9 / (HBM_PEAK_GBPS * world), 4))
+
+    cpu_baseline = None
+    if rank == 0 and args.cpu_baseline_seconds > 0:
+        cpu_baseline = run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail)
+
+    if rank == 0:
+        out = {
+            "metric": "sampled edges/s (+ feature GB/s), 3-hop GraphSAGE mini-batch pipeline" if H == 3 else f"sampled edges/s (+ feature GB/s), {H}-hop mini-batch pipeline",
+            "value": round(job_edges / elapsed_max, 1),
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": K_steps,
+            "warmup": W,
+            "ms_per_step": round(elapsed_max / K_steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32 ids / f32 rows (verbatim copy)",
+            "data": "synthetic",
+            "config": {"workload": f"{spec.name}-shape synthetic graph, {H}-hop fan-out {fan}, batch {B}, CSR + features resident in HBM (Kg=1 replicas)",
+                       "V": V, "E": E, "F": F, "batch": B, "fanout": fan, "gather": args.gather, "seeds_per_rank": n_mine,
+                       "parallelism": f"dp{world} (seed shards tid % {world}, no data-path collective)"},
+            "feature_GBps": round(job_nodes * 4 * F / elapsed_max / 1e9, 2),
+            "batches_per_s": round(K_steps * world / elapsed_max, 2),
+            "edges_per_batch": round(job_edges / (K_steps * world), 1),
+            "unique_nodes_per_batch": round(job_nodes / (K_steps * world), 1),
+            "graph_gen_s": round(gen_s, 2),
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail):
+    """The CPU oracle (reference semantics, scalar C, 1 thread) timed on the host cores on a bounded
+    sample of the SAME workload: the first few batches of rank 0's seed list."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    t0 = time.time()
+    h_indptr = indptr.cpu().numpy()
+    h_indices = indices.cpu().numpy()
+    with_feat = not args.no_cpu_features
+    h_feats = feats.cpu().numpy() if with_feat else None
+    h_ids = mine.cpu().numpy()
+    h_lab = my_labels.cpu().numpy()
+    copy_s = time.time() - t0
+    runner = O.OracleRunner(h_indptr, h_indices, h_feats, spec.V, spec.F, B, fan, with_features=with_feat)
+    edges, n, t_used = 0, 0, 0.0
+    H = len(fan)
+    while t_used < args.cpu_baseline_seconds and n < min(steps_avail, 64):
+        t1 = time.perf_counter()
+        res = runner.run_batch(h_ids, h_lab, n)
+        t_used += time.perf_counter() - t1
+        edges += int(res["ec"][2 + H])
+        n += 1
+    return {"value": round(edges / t_used, 1), "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{n} batches (batch {B}, fan-out {fan}) of the same workload, oracle/legion_oracle.c single thread"
+                      + ("" if with_feat else ", sampler+COO only (no feature gather)"),
+            "seconds": round(t_used, 2), "host_copy_s": round(copy_s, 1), "host_cores_available": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,12 @@ void d_copy_d_2_h(void* h_ptr, const void* d_ptr, int64_t num_bytes);
 void d_stream_sync(void* stream);
 void* d_stream_create(void);
 void d_stream_destroy(void* stream);
+void d_copy_async(void* dst, const void* src, int64_t num_bytes, void* stream); /* hipMemcpyDefault */
+void d_memset_async(void* dst, int value, int64_t num_bytes, void* stream);
+void* d_event_create(void);                       /* timing-enabled hipEvent_t */
+void d_event_destroy(void* event);
+void d_event_record(void* event, void* stream);
+float d_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop` */
 
 /* ---- BuildInfo: src/BuildInfo.h:5-70 (the fields the hot path uses; BaM/SSD fields dropped) */
 typedef struct LegionBuildInfo {

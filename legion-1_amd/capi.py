@@ -64,6 +64,12 @@ _SIGS = {
     "d_stream_sync": (None, [vp]),
     "d_stream_create": (vp, []),
     "d_stream_destroy": (None, [vp]),
+    "d_copy_async": (None, [vp, vp, i64, vp]),
+    "d_memset_async": (None, [vp, C.c_int, i64, vp]),
+    "d_event_create": (vp, []),
+    "d_event_destroy": (None, [vp]),
+    "d_event_record": (None, [vp, vp]),
+    "d_event_elapsed_ms": (C.c_float, [vp, vp]),
     "SetGPUDevice": (None, [i32]),
     "GetGPUDevice": (i32, []),
     "NewGPUMemoryGraphStorage": (vp, []),

@@ -122,6 +122,29 @@ void* d_stream_create(void)
     return (void*)s;
 }
 void d_stream_destroy(void* stream) { (void)hipStreamDestroy((hipStream_t)stream); }
+void d_copy_async(void* dst, const void* src, int64_t num_bytes, void* stream)
+{
+    HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)num_bytes, hipMemcpyDefault, (hipStream_t)stream));
+}
+void d_memset_async(void* dst, int value, int64_t num_bytes, void* stream)
+{
+    HIP_CHECK(hipMemsetAsync(dst, value, (size_t)num_bytes, (hipStream_t)stream));
+}
+void* d_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    HIP_CHECK(hipEventCreate(&e));
+    return (void*)e;
+}
+void d_event_destroy(void* event) { (void)hipEventDestroy((hipEvent_t)event); }
+void d_event_record(void* event, void* stream) { HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); }
+float d_event_elapsed_ms(void* start, void* stop)
+{
+    float ms = 0.f;
+    HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+    HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return ms;
+}
 
 void legion_rng_probe(void* stream, const int32_t* idx, const int32_t* deg, int32_t* k_out, int32_t n)
 {

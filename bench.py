@@ -93,7 +93,8 @@ def main():
     all_train = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
     L.legion_synth_seed_ids(None, all_train.data_ptr(), 0, spec.n_train, V, spec.M2, spec.C2, 1, 0)
     torch.cuda.synchronize()
-    mine = all_train[(all_train % world) == rank].contiguous()
+    import legion1_amd.dist as D
+    mine = D.shard_seeds(all_train, rank, world).contiguous()
     del all_train
     labels_all = torch.empty(V, dtype=torch.int32, device=dev)
     L.legion_synth_labels(None, labels_all.data_ptr(), 0, V, spec.classes)
@@ -107,6 +108,7 @@ def main():
     eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=1,
                    csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E)
     eng.alloc_features()
+    L.GPUCache_SetPreSc(eng.cache, 0)  # steady state: no pre-sampling epoch in the all-resident configuration
     stream = L.d_stream_create()
     steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
     K_steps, W = args.steps, args.warmup
@@ -170,16 +172,9 @@ def main():
     gather_bytes = nodes * (8 * F + 8)
     tot_edges, tot_nodes = int(edges.sum()), int(nodes.sum())
 
-    stats = torch.tensor([elapsed, float(tot_edges), float(tot_nodes), float(samp_bytes.sum() + gather_bytes.sum())],
-                         dtype=torch.float64, device=dev)
-    if world > 1:
-        mx = stats.clone()
-        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(stats, op=torch.distributed.ReduceOp.SUM)
-        elapsed_max = float(mx[0].item())
-    else:
-        elapsed_max = elapsed
-    job_edges, job_nodes, job_bytes = float(stats[1].item()), float(stats[2].item()), float(stats[3].item())
+    import legion1_amd.dist as D
+    elapsed_max, (job_edges, job_nodes, job_bytes) = D.aggregate(
+        elapsed, [tot_edges, tot_nodes, float(samp_bytes.sum() + gather_bytes.sum())], world, device=dev)
 
     # dominant kernel (k_gather: it moves ~90 % of the batch's algorithmic bytes), HIP events on our stream
     roofline = None

@@ -204,6 +204,9 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
                         const uint64_t* counters, int32_t train_step);
 /* Skip the cost model and impose capacities (rows per GPU) for every clique. */
 void GPUCache_SetCapacity(GPUCache* c, int32_t node_capacity, int32_t edge_capacity);
+/* is_presc_ (GPUCache.cuh:160): true until CandidateSelection ran; a server that skips the
+ * pre-sampling epoch (everything resident, no cache) clears it explicitly. */
+void GPUCache_SetPreSc(GPUCache* c, int is_presc);
 void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph);
 int32_t GPUCache_MaxIdNum(const GPUCache* c, int32_t dev_id);
 float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);

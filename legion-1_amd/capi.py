@@ -113,6 +113,7 @@ _SIGS = {
     "GPUCache_CandidateSelection": (None, [vp, C.c_int, vp, vp]),
     "GPUCache_CostModel": (None, [vp, C.c_int, vp, vp, vp, i32]),
     "GPUCache_SetCapacity": (None, [vp, i32, i32]),
+    "GPUCache_SetPreSc": (None, [vp, C.c_int]),
     "GPUCache_FillUp": (None, [vp, C.c_int, vp, vp]),
     "GPUCache_MaxIdNum": (i32, [vp, i32]),
     "GPUCache_Float_Feature_Cache": (vp, [vp, i32]),

@@ -189,6 +189,8 @@ void GPUCache_CandidateSelection(GPUCache* c, int cache_agg_mode, GPUNodeStorage
     c->is_presc = false;
 }
 
+void GPUCache_SetPreSc(GPUCache* c, int is_presc) { if (c) c->is_presc = is_presc != 0; }
+
 void GPUCache_SetCapacity(GPUCache* c, int32_t node_capacity, int32_t edge_capacity)
 {
     c->capacity_forced = true;

@@ -1,0 +1,52 @@
+"""One-process-per-GPU plumbing shared by bench.py and the tests.
+
+The path shards by independent units: rank r of N samples the seeds with ``tid % N == r``
+(GPUGraphStore.cu:332-346, validation/test always use ``tid % N``) and there is no collective on
+the data path.  ``torch.distributed`` (nccl == RCCL on ROCm, gloo on CPU) is only used for the
+start/stop barriers and to add up the per-rank totals.
+"""
+from __future__ import annotations
+
+import os
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def shard_seeds(ids, rank: int, world: int, partition_index=None, use_partition: bool = False):
+    """Seeds of ``rank``: order preserving filter.  Works on numpy arrays and torch tensors."""
+    if use_partition and partition_index is not None:
+        part = partition_index[ids.long()] if hasattr(ids, "long") else partition_index[ids]
+    else:
+        part = ids % world
+    return ids[part == rank]
+
+
+def train_steps(n_seeds_per_rank, batch_size: int) -> int:
+    """train_step = (min_g n_train_g - 1) / B   (CUDA_IPC_Service.cu:81-89: floor, tail dropped)."""
+    return (min(n_seeds_per_rank) - 1) // batch_size
+
+
+def barrier(world: int):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def aggregate(elapsed_s: float, totals, world: int, device=None):
+    """(max over ranks of elapsed, element-wise sum over ranks of totals)."""
+    if world <= 1:
+        return float(elapsed_s), [float(t) for t in totals]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    s = torch.tensor([float(x) for x in totals], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    return float(t.item()), [float(x) for x in s.tolist()]
+
+
+def throughput_line(job_units: float, elapsed_max_s: float, steps: int):
+    """whole-job units/s and ms per step from the aggregated numbers."""
+    return job_units / elapsed_max_s, elapsed_max_s / steps * 1e3

@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    import json
+    with open(os.path.join(GOLDEN, name + ".json")) as f:
+        return json.load(f)
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def assert_batch_equal(ref, got, keys=("nc", "ec", "ids", "labels", "src_off", "dst_off", "features")):
+    for k in keys:
+        if k not in ref or k not in got:
+            continue
+        a, b = np.asarray(ref[k]), np.asarray(got[k])
+        assert a.shape == b.shape, f"{k}: shape {a.shape} vs {b.shape}"
+        if not np.array_equal(a, b):
+            bad = np.nonzero(a.reshape(-1) != b.reshape(-1))[0]
+            raise AssertionError(f"{k}: {len(bad)} mismatches, first at {bad[:5]}: {a.reshape(-1)[bad[:5]]} vs {b.reshape(-1)[bad[:5]]}")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def synth():
+    import legion1_amd.synth as S
+    return S
+
+
+@pytest.fixture(scope="session")
+def small_ds(synth):
+    spec = synth.spec_for("products", scale=0.01)
+    return synth.generate(spec)

@@ -1,0 +1,53 @@
+"""Trainer-side process of the IPC hand-off test: consumes every batch through the `ipc_service`
+module exactly like legion_graphsage.py does (train_one_step, legion_graphsage.py:72-89) and writes
+one digest record per batch.  usage: ipc_client.py <feature_dim> <epochs> <out.json>"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "legion-1_amd", "ipc_service"))
+import ipc_service  # noqa: E402
+
+
+def sha(t):
+    return hashlib.sha256(np.ascontiguousarray(t.cpu().numpy()).tobytes()).hexdigest()
+
+
+def main():
+    feat_dim, epochs, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    torch.cuda.set_device(0)
+    ipc_service.initialize()
+    train_steps, valid_steps, test_steps = ipc_service.get_steps()
+    hops = ipc_service.get_hops()
+    total = (train_steps + valid_steps) * epochs + test_steps
+    recs = []
+    for b in range(total):
+        tensors = ipc_service.get_next(feat_dim)
+        sizes = ipc_service.get_block_size()
+        ids, feats, labels = tensors[:3]
+        blocks = tensors[3:]
+        assert len(blocks) == 2 * hops and feats.shape == (ids.shape[0], feat_dim)
+        assert ids.device.type == "cuda" and ids.dtype == torch.int32 and feats.dtype == torch.float32
+        # the DGL blocks of the trainers: block k is (src nodes, dst nodes, edges); b2_* alias b1_* prefixes
+        for k in range(hops):
+            src, dst = blocks[2 * k], blocks[2 * k + 1]
+            assert src.data_ptr() == blocks[0].data_ptr() and dst.data_ptr() == blocks[1].data_ptr()
+            if src.numel():
+                assert int(src.max()) < sizes[2 * k] and int(dst.max()) < sizes[2 * k + 1]
+        torch.cuda.synchronize()
+        recs.append(dict(b=b, n=int(ids.shape[0]), sizes=list(sizes), ids=sha(ids), features=sha(feats), labels=sha(labels),
+                         edges=[int(blocks[2 * k].numel()) for k in range(hops)],
+                         src=sha(blocks[0]), dst=sha(blocks[1])))
+        ipc_service.synchronize()
+    ipc_service.finalize()
+    with open(out, "w") as f:
+        json.dump(dict(steps=[train_steps, valid_steps, test_steps], hops=hops, batches=recs), f)
+
+
+if __name__ == "__main__":
+    main()

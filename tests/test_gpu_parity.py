@@ -1,0 +1,399 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes over liblegion_amd.so),
+against the CPU oracle on the same seeded inputs -- bit exact for every id / index / counter and
+for the (verbatim copied) f32 feature rows.  Run on the GPU box with `pytest -m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_batch_equal, load_golden, sha
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import legion1_amd.capi as K
+    L = K.lib()
+    L.legion_set_error_mode(K.ERR_RETURN)
+    L.SetGPUDevice(0)
+    return K
+
+
+def make_engine(K, ds_or_arrays, B, fan, G=1, seeds=None, **kw):
+    if hasattr(ds_or_arrays, "spec"):
+        ds = ds_or_arrays
+        V, F, indptr, indices, feats = ds.spec.V, ds.spec.F, ds.indptr, ds.indices, ds.features
+        if seeds is None:
+            import oracle as O
+            parts = O.split_seeds(ds.train, G)
+            seeds = dict(train=[(p, ds.labels[p]) for p in parts])
+    else:
+        V, F, indptr, indices, feats = ds_or_arrays
+    eng = K.Engine(indptr, indices, feats, V, F, seeds, B, fan, G=G, **kw)
+    eng.alloc_features()
+    return eng
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_rng_on_gpu_matches_thrust_vectors(K):
+    kat = load_golden("rng_kat")
+    rows = np.array(kat["rows"], dtype=np.int64)
+    idx, deg = rows[:, 0].astype(np.int32), rows[:, 1].astype(np.int32)
+    di, dd, dk = K.DevBuf.from_numpy(idx), K.DevBuf.from_numpy(deg), K.DevBuf(idx.nbytes)
+    K.lib().legion_rng_probe(None, di.ptr, dd.ptr, dk.ptr, len(idx))
+    K.lib().d_stream_sync(None)
+    K.check()
+    assert np.array_equal(dk.to_numpy(np.int32, len(idx)), rows[:, 2].astype(np.int32))
+    for b in (di, dd, dk):
+        b.free()
+
+
+def test_toy_golden(K, oracle):
+    g = load_golden("toy_batches")
+    V, F = g["V"], g["F"]
+    indptr, indices = np.array(g["indptr"], np.int64), np.array(g["indices"], np.int32)
+    feats = np.array(g["features"], np.float32).reshape(V, F)
+    labels, seeds = np.array(g["labels"], np.int32), np.array(g["seeds"], np.int32)
+    for case in g["cases"]:
+        eng = make_engine(K, (V, F, indptr, indices, feats), case["batch"], case["fanout"],
+                          seeds=dict(train=[(seeds, labels[seeds])]))
+        eng.run_batch(0, case["counter"])
+        got = eng.result(0)
+        eng.close()
+        for k in ("nc", "ec", "ids", "labels", "src_off", "dst_off"):
+            assert got[k].tolist() == case[k], (case["fanout"], k)
+        assert sha(got["features"]) == case["features_sha256"]
+
+
+def test_medium_digests(K, synth):
+    g = load_golden("medium_digests")
+    ds = synth.generate(synth.spec_for("products", scale=0.04))
+    engines = {}
+    for case in g["cases"]:
+        key = (case["batch"], tuple(case["fanout"]))
+        if key not in engines:
+            engines[key] = make_engine(K, ds, case["batch"], case["fanout"])
+        eng = engines[key]
+        eng.run_batch(0, case["counter"])
+        got = eng.result(0)
+        assert got["nc"].tolist() == case["nc"] and got["ec"].tolist() == case["ec"], key
+        for k in ("ids", "labels", "src_off", "dst_off", "features"):
+            assert sha(got[k]) == case[k + "_sha256"], (key, k)
+    for e in engines.values():
+        e.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_graphs_with_holes(K, oracle, seed):
+    """degree-0 rows, -1 neighbour entries, degree < fan-out, short last batch, batch of one."""
+    rng = np.random.RandomState(seed)
+    V, F = 500, 7 + seed           # odd F -> scalar gather path; F=8 (seed 1) -> float4 path
+    deg = rng.randint(0, 12, size=V)
+    deg[rng.randint(0, V, 5)] = 300
+    indptr = np.zeros(V + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    indices = rng.randint(-1, V, size=int(indptr[-1])).astype(np.int32)
+    feats = rng.rand(V, F).astype(np.float32)
+    labels = rng.randint(0, 9, size=V).astype(np.int32)
+    seeds = rng.permutation(V)[:203].astype(np.int32)
+    for fan, B in (([3, 2], 50), ([5, 4, 3], 64), ([25, 10], 203), ([1, 1, 1, 1], 7), ([2], 1)):
+        orc = oracle.OracleRunner(indptr, indices, feats, V, F, B, fan)
+        eng = make_engine(K, (V, F, indptr, indices, feats), B, fan, seeds=dict(train=[(seeds, labels[seeds])]))
+        for counter in range((len(seeds) + B - 1) // B):
+            ref = orc.run_batch(seeds, labels[seeds], counter)
+            eng.run_batch(0, counter)
+            assert_batch_equal(ref, eng.result(0))
+        eng.close()
+
+
+def test_modes_and_padding(K, oracle, small_ds):
+    """valid / test seed sets, the size*counter offset quirk of a short last batch (Kernels.cu:224-227)."""
+    ds = small_ds
+    V, F = ds.spec.V, ds.spec.F
+    seeds = dict(train=[(ds.train, ds.labels[ds.train])], valid=[(ds.valid, ds.labels[ds.valid])],
+                 test=[(ds.test[:1000], ds.labels[ds.test[:1000]])])
+    B, fan = 300, [10, 5]
+    eng = make_engine(K, ds, B, fan, seeds=seeds)
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, V, F, B, fan)
+    for mode, (ids, labs) in ((0, seeds["train"][0]), (1, seeds["valid"][0]), (2, seeds["test"][0])):
+        n_batches = (len(ids) + B - 1) // B
+        for counter in (0, n_batches - 1):
+            ref = orc.run_batch(ids, labs, counter, mode=mode)
+            eng.run_batch(0, counter, mode=mode)
+            assert_batch_equal(ref, eng.result(0))
+    eng.close()
+
+
+def test_host_pinned_tables_equal_device_tables(K, oracle, small_ds):
+    """CSR + features in pinned host memory read through the GPU's host mapping (the reference's UVA
+    configuration, GPUGraphStore.cu:264-265,315) give the same bytes as HBM-resident tables."""
+    ds = small_ds
+    B, fan = 500, [25, 10]
+    ref = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan).run_batch(ds.train, ds.labels[ds.train], 0)
+    for loc in (K.LOC_HOST_PINNED, K.LOC_HOST_PAGEABLE, K.LOC_DEVICE):
+        eng = make_engine(K, ds, B, fan, csr_location=loc, features_location=loc)
+        eng.run_batch(0, 0)
+        assert_batch_equal(ref, eng.result(0))
+        eng.close()
+
+
+def test_per_level_and_single_gather_agree(K, oracle, small_ds):
+    ds = small_ds
+    B, fan = 400, [10, 5, 3]
+    ref = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan).run_batch(ds.train, ds.labels[ds.train], 2)
+    eng = make_engine(K, ds, B, fan)
+    for per_level in (True, False):
+        eng.run_batch(0, 2, per_level=per_level)
+        assert_batch_equal(ref, eng.result(0))
+    eng.close()
+
+
+def test_back_to_back_batches_without_planner(K, oracle, small_ds):
+    """The position table is wiped lazily when the planner op did not run; two pipes alternate."""
+    ds = small_ds
+    B, fan = 200, [10, 5]
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan, pipeline_depth=2)
+    for it in range(5):
+        ref = orc.run_batch(ds.train, ds.labels[ds.train], it)
+        eng.run_batch(0, it, plan=(it % 2 == 0), pipe=it % 2)
+        assert_batch_equal(ref, eng.result(0, pipe=it % 2))
+    eng.close()
+
+
+def test_operator_plugin_api(K, oracle, small_ds):
+    """The reference's Operator objects (Operator.h:4-27) driven the way GPURunner::RunOnce does."""
+    ds = small_ds
+    B, fan = 300, [10, 5]
+    L = K.lib()
+    eng = make_engine(K, ds, B, fan)
+    info = eng.info
+    env = L.NewIPCEnv(1)
+    ns_steps = L.IPCEnv_Coordinate(env, C.byref(info))
+    ops = [L.NewBatchGenerator(0), L.NewFeatureExtractor(1), L.NewRandomSampler(2), L.NewFeatureExtractor(3),
+           L.NewRandomSampler(4), L.NewFeatureExtractor(5), L.NewCachePlanner(6), L.NewCacheUpdater(7)]
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    params = []
+    for i in range(8):
+        p = K.OpParams()
+        p.device_id, p.stream, p.event = 0, None, None
+        p.memorypool, p.cache, p.graph, p.noder, p.env = eng.pools[0], eng.cache, eng.graph, eng.noder, env
+        p.neighbor_count = fan[(i - 2) // 2] if i in (2, 4) else 0
+        p.is_presc, p.in_memory = 0, 1
+        params.append(p)
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    for it in (0, 3):
+        L.GPUMemoryPool_SetCurrentMode(eng.pools[0], 0)
+        L.GPUMemoryPool_SetIter(eng.pools[0], it)
+        for op, p in zip(ops, params):
+            L.Operator_run(op, C.byref(p))
+        L.d_stream_sync(None)
+        K.check()
+        assert_batch_equal(orc.run_batch(ds.train, ds.labels[ds.train], it), eng.result(0))
+    for op in ops:
+        L.Operator_Delete(op)
+    L.IPCEnv_Finalize(env)
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# cache: pre-sampling, ranking, cost model, fill-up, unified cache with Kg logical GPUs on one device
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("G,mode", [(1, 0), (2, 1), (4, 2), (4, 1)])
+def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode):
+    ds = small_ds
+    V, F = ds.spec.V, ds.spec.F
+    L = K.lib()
+    B, fan = 250, [10, 5]
+    Kg = {0: 1, 1: 2, 2: 4}[mode]
+    parts = oracle.split_seeds(ds.train, G)
+    steps = min((len(p) - 1) // B for p in parts)
+    counters = [500000, 250000]               # stand-ins for the two Intel-PCM PCIe counters (Server.cu:100)
+    budget = int(V * F * 4 * 0.15)
+    eng = make_engine(K, ds, B, fan, G=G, cache_memory=budget, train_step=steps)
+    orcs = [oracle.OracleRunner(ds.indptr, ds.indices, ds.features, V, F, B, fan, partition_count=G) for _ in range(G)]
+    max_ids = []
+    for g in range(G):      # pre-sampling epoch (Server.cu:83-95): even ops only, hotness collected
+        seen = 0
+        for it in range(steps):
+            eng.run_batch(g, it, is_presc=True)
+            ref = orcs[g].run_batch(parts[g], ds.labels[parts[g]], it, is_presc=True)
+            assert_batch_equal(ref, eng.result(g, with_features=False))
+            seen = max(seen, int(ref["nc"][5 + 2 * len(fan)]))
+        L.SetGPUDevice(g)
+        assert np.array_equal(K.read_dev(L.GPUCache_GetNodeAccessedMap(eng.cache, g), np.uint64, V), orcs[g].node_access_time)
+        assert np.array_equal(K.read_dev(L.GPUCache_GetEdgeAccessedMap(eng.cache, g), np.uint64, V), orcs[g].edge_access_time)
+        assert L.GPUCache_MaxIdNum(eng.cache, g) == seen      # max_ids_ (GPUCache.cu:294-296)
+        max_ids.append(seen)
+    # ranking + cost model with explicit counters + fill-up
+    eng.build_cache(cache_agg_mode=mode, counters=counters, train_step=steps)
+    assert L.GPUCache_Kg(eng.cache) == Kg and L.GPUCache_Kc(eng.cache) == G // Kg
+    for Ki in range(G // Kg):
+        members = list(range(Ki * Kg, (Ki + 1) * Kg))
+        AF, QF = oracle.candidate_selection([orcs[m].node_access_time for m in members], V)
+        AT, QT = oracle.candidate_selection([orcs[m].edge_access_time for m in members], V)
+        L.SetGPUDevice(Ki * Kg)
+        assert np.array_equal(K.read_dev(L.GPUCache_GetQF(eng.cache, Ki), np.int32, V), QF)
+        assert np.array_equal(K.read_dev(L.GPUCache_GetQT(eng.cache, Ki), np.int32, V), QT)
+        cm = oracle.cost_model(AF, AT, QT, ds.indptr, V, F, budget, Kg, counters, [max_ids[m] for m in members], steps)
+        assert L.GPUCache_NodeCapacity(eng.cache, Ki * Kg) == cm["node_capacity"]
+        assert L.GPUCache_EdgeCapacity(eng.cache, Ki * Kg) == cm["edge_capacity"]
+        assert abs(L.GPUCache_Alpha(eng.cache, Ki) - cm["alpha_idx"] * 0.01) < 1e-9
+        for m in members:
+            orcs[m].set_feature_cache(QF, cm["node_capacity"], Kg)
+            orcs[m].set_topo_cache(QT, cm["edge_capacity"], Kg, Ki)
+        # FindFeat / FindTopo against the oracle's maps, cache rows and CSR fragments
+        probe = np.concatenate([QF[:50], QT[:50], np.arange(0, V, 97, dtype=np.int32), np.array([-1], np.int32)])
+        for m in members:
+            L.SetGPUDevice(m)
+            d_in = K.DevBuf.from_numpy(probe)
+            d_nc = K.DevBuf.from_numpy(np.array([0, 0, 0, 0, len(probe)] + [0] * 11, np.int32))
+            d_out, d_pi, d_po = K.DevBuf(len(probe) * 4), K.DevBuf(len(probe)), K.DevBuf(len(probe) * 4)
+            L.GPUCache_FindFeat(eng.cache, d_in.ptr, d_out.ptr, d_nc.ptr, 1, None, m)
+            L.GPUCache_FindTopo(eng.cache, d_in.ptr, d_pi.ptr, d_po.ptr, len(probe), 2, None, m)
+            L.d_stream_sync(None)
+            safe = np.where(probe >= 0, probe, 0)
+            assert np.array_equal(d_out.to_numpy(np.int32, len(probe)), np.where(probe >= 0, orcs[m].node_map[safe], -1))
+            assert np.array_equal(d_pi.to_numpy(np.int8, len(probe)), np.where(probe >= 0, orcs[m].part_index_map[safe], -1))
+            assert np.array_equal(d_po.to_numpy(np.int32, len(probe)), np.where(probe >= 0, orcs[m].part_offset_map[safe], -1))
+            j = m - Ki * Kg
+            cache_rows = K.read_dev(L.GPUCache_Float_Feature_Cache(eng.cache, m), np.float32, cm["node_capacity"] * F).reshape(-1, F)
+            n_valid = len(range(j, min(V, cm["node_capacity"] * Kg), Kg))
+            assert np.array_equal(cache_rows[:n_valid], orcs[m].caches[j][:n_valid])
+            fi = K.read_dev(L.GPUGraphStorage_GetFragmentIndex(eng.graph, m, m), np.int64, cm["edge_capacity"] + 1)
+            assert np.array_equal(fi, orcs[m].frag_indptr[m])
+            fx = K.read_dev(L.GPUGraphStorage_GetFragmentMatrix(eng.graph, m, m), np.int32, int(fi[-1]))
+            assert np.array_equal(fx, orcs[m].frag_indices[m][:int(fi[-1])])
+            for b in (d_in, d_nc, d_out, d_pi, d_po):
+                b.free()
+    # steady state through the unified cache (local + peer shards + backing-table misses)
+    for g in range(G):
+        for it in (0, 1):
+            for m_mode, ids in ((0, parts[g]),):
+                ref = orcs[g].run_batch(ids, ds.labels[ids], it, mode=m_mode)
+                eng.run_batch(g, it, mode=m_mode)
+                got = eng.result(g)
+                assert_batch_equal(ref, got)
+                hit = orcs[g].node_map[got["ids"]] >= 0
+                assert 0 < hit.sum() < len(hit)
+    eng.close()
+
+
+def test_cost_model_everything_fits(K, small_ds):
+    """Budget >= all features + all adjacency: cache everything (the reference degenerates here,
+    GPUCache.cu:744-751 -- documented extension)."""
+    ds = small_ds
+    eng = make_engine(K, ds, 100, [5, 5], G=2, cache_memory=1 << 40)
+    for g in range(2):
+        eng.run_batch(g, 0, is_presc=True)
+    eng.build_cache(cache_agg_mode=1)
+    L = K.lib()
+    assert L.GPUCache_NodeCapacity(eng.cache, 0) == ds.spec.V // 2 + 1 == L.GPUCache_EdgeCapacity(eng.cache, 1)
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# generator + full-size runs (BASELINE.json shapes): size-independent properties
+# ---------------------------------------------------------------------------------------------------
+def test_gpu_generator_matches_numpy(K, synth):
+    import torch
+    L = K.lib()
+    spec = synth.spec_for("papers100M", scale=0.002)
+    ds = synth.generate(spec)
+    dev = torch.device("cuda", 0)
+    deg = torch.empty(spec.V, dtype=torch.int64, device=dev)
+    lad = np.ascontiguousarray(spec.ladder, dtype=np.int32)
+    L.legion_synth_degrees(None, deg.data_ptr(), 0, spec.V, lad.ctypes.data)
+    ind = torch.empty(ds.E, dtype=torch.int32, device=dev)
+    L.legion_synth_neighbors(None, ind.data_ptr(), 0, ds.E, spec.V, spec.M, spec.C)
+    ft = torch.empty((spec.V, spec.F), dtype=torch.float32, device=dev)
+    L.legion_synth_features(None, ft.data_ptr(), 0, spec.V, spec.F)
+    lb = torch.empty(spec.V, dtype=torch.int32, device=dev)
+    L.legion_synth_labels(None, lb.data_ptr(), 0, spec.V, spec.classes)
+    tr = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
+    L.legion_synth_seed_ids(None, tr.data_ptr(), 0, spec.n_train, spec.V, spec.M2, spec.C2, 1, 0)
+    torch.cuda.synchronize()
+    K.check()
+    assert np.array_equal(deg.cpu().numpy(), np.diff(ds.indptr))
+    assert np.array_equal(ind.cpu().numpy(), ds.indices)
+    assert np.array_equal(ft.cpu().numpy(), ds.features)
+    assert np.array_equal(lb.cpu().numpy(), ds.labels)
+    assert np.array_equal(tr.cpu().numpy(), ds.train)
+
+
+@pytest.mark.parametrize("workload,fan", [("products", [25, 10, 5]), ("papers100M", [25, 10, 5]), ("papers100M", [25, 10])])
+def test_full_size_properties(K, synth, workload, fan):
+    """BASELINE.json sizes (V up to 111 M, ~64 GB resident): the oracle cannot run there in seconds,
+    so check the size-independent properties every reference execution satisfies."""
+    import torch
+    sys_bench = __import__("bench")
+    L = K.lib()
+    spec = synth.spec_for(workload)
+    dev = torch.device("cuda", 0)
+    indptr, indices, feats, E = sys_bench.build_graph_on_gpu(K, spec, dev)
+    B, H = 8000, len(fan)
+    tr = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
+    L.legion_synth_seed_ids(None, tr.data_ptr(), 0, spec.n_train, spec.V, spec.M2, spec.C2, 1, 0)
+    lab = torch.empty(spec.V, dtype=torch.int32, device=dev)
+    L.legion_synth_labels(None, lab.data_ptr(), 0, spec.V, spec.classes)
+    torch.cuda.synchronize()
+    my_lab = lab[tr.long()].contiguous()
+    seeds = dict(train=[((tr.data_ptr(), spec.n_train), (my_lab.data_ptr(), spec.n_train))])
+    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), spec.V, spec.F, seeds, B, fan, E=E)
+    eng.alloc_features()
+    for it in (0, 7):
+        eng.run_batch(0, it)
+        res = eng.result(0)
+        nc, ec, ids = res["nc"], res["ec"], res["ids"]
+        levels = [int(nc[4 + 2 * l]) for l in range(H + 1)]
+        assert nc[5 + 2 * H] == sum(levels) == len(ids) and levels[0] == B
+        assert len(np.unique(ids)) == len(ids) and ids.min() >= 0 and ids.max() < spec.V       # dedup
+        assert np.array_equal(ids[:B], synth.seed_ids(spec, it * B, (it + 1) * B))
+        assert np.array_equal(res["labels"], synth.labels(spec, ids[:B]))
+        src, dst = res["src_off"], res["dst_off"]
+        cum_nodes, e0 = np.cumsum(levels), 0
+        for h in range(1, H + 1):
+            e1 = int(ec[2 + h])
+            assert (dst[e0:e1] < cum_nodes[h - 1]).all() and (src[e0:e1] < cum_nodes[h]).all() and (src[e0:e1] >= 0).all()
+            if h > 1:   # hop h expands every endpoint of hop h-1 in order: dst offsets are non-decreasing runs
+                assert (np.diff(dst[e0:e1].astype(np.int64)) != 0).sum() <= e1 - e0
+            e0 = e1
+        # first-seen order: a new node's position is increasing with the edge that discovered it
+        first_edge = np.full(len(ids), -1, np.int64)
+        order = np.arange(len(src) - 1, -1, -1)
+        first_edge[src[order]] = order
+        new_nodes = np.arange(B, len(ids))
+        fe = first_edge[new_nodes]
+        assert (fe >= 0).all() and (np.diff(fe) > 0).all()
+        # hop-1 edge multiset == closed form (RNG stream depends only on the slot index)
+        ip = indptr[torch.from_numpy(ids[:B].astype(np.int64)).to(dev)].cpu().numpy()
+        ip1 = indptr[torch.from_numpy(ids[:B].astype(np.int64) + 1).to(dev)].cpu().numpy()
+        deg = (ip1 - ip)
+        assert int(np.minimum(deg, fan[0]).sum()) == int(ec[3])
+        import oracle as O
+        e = 0
+        for i in list(range(0, B, 997)):
+            base = int(np.minimum(deg[:i], fan[0]).sum())
+            for j in range(min(int(deg[i]), fan[0])):
+                k = O.sample_index(i * fan[0] + j, int(deg[i]))
+                want = int(indices[int(ip[i]) + k].item())
+                assert ids[src[base + j]] == want and dst[base + j] == i
+                e += 1
+        assert e > 0
+        # every sampled edge is an edge of the graph (sample)
+        rs = np.random.RandomState(it)
+        for eidx in rs.choice(len(src), size=300, replace=False):
+            d_id, s_id = int(ids[dst[eidx]]), int(ids[src[eidx]])
+            row = indices[int(indptr[d_id].item()):int(indptr[d_id + 1].item())].cpu().numpy()
+            assert s_id in row
+        # gathered rows are the table rows, byte for byte (generator closed form)
+        rows = rs.choice(len(ids), size=2000, replace=False)
+        assert np.array_equal(res["features"][rows], synth.features(spec, ids[rows]))
+        assert sha(res["features"][:B]) == sha(synth.features(spec, ids[:B]))
+    # idempotence: the same batch index gives the same bytes again
+    eng.run_batch(0, 0)
+    again = eng.result(0)
+    eng.run_batch(0, 0)
+    assert_batch_equal(again, eng.result(0))
+    eng.close()

@@ -1,0 +1,157 @@
+"""Host-side logic on CPU: step schedule (S11), seed split (S10), cache placement / ranking /
+cost model (S6, S8), fragments (S9), the synthetic generator and the on-disk layout."""
+import os
+
+import numpy as np
+
+from conftest import load_golden, sha
+
+
+def test_schedule_table(oracle, synth):
+    for row in load_golden("schedule_table"):
+        steps, tb, vb, sb = oracle.coordinate(row["train_num"], row["valid_num"], row["test_num"], 8000)
+        assert steps.tolist() == row["steps"] and vb.tolist() == row["valid_bs"] and sb.tolist() == row["test_bs"]
+        assert (tb == 8000).all()
+        # train_step floors and drops the tail; valid/test ceil to 512-sized steps (CUDA_IPC_Service.cu:89-117)
+        assert steps[0] == (min(row["train_num"]) - 1) // 8000
+        assert steps[1] == (max(row["valid_num"]) - 1) // 512 + 1
+        assert oracle.max_step(steps, row["epoch"]) == row["max_step"] == (steps[0] + steps[1]) * row["epoch"] + steps[2]
+        for b, (mode, local) in zip(row["probe"], row["mode_local"]):
+            assert list(oracle.schedule(steps, row["epoch"], b)) == [mode, local]
+
+
+def test_schedule_modes(oracle):
+    steps = np.array([3, 2, 4], np.int32)
+    seq = [oracle.schedule(steps, 2, b) for b in range(oracle.max_step(steps, 2))]
+    assert seq == [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1)] * 2 + [(2, 0), (2, 1), (2, 2), (2, 3)]
+
+
+def test_split_seeds(oracle):
+    ids = np.array([5, 2, 9, 4, 7, 12, 1], np.int32)
+    parts = oracle.split_seeds(ids, 2)
+    assert parts[0].tolist() == [2, 4, 12] and parts[1].tolist() == [5, 9, 7, 1]
+    part_idx = np.zeros(16, np.int32)
+    part_idx[[5, 9]] = 1
+    part_idx[7] = 3                       # >= G: dropped (GPUGraphStore.cu:343)
+    parts = oracle.split_seeds(ids, 2, part_idx, 1)
+    assert parts[0].tolist() == [2, 4, 12, 1] and parts[1].tolist() == [5, 9]
+    import legion1_amd.dist as D
+    for r in range(3):
+        assert D.shard_seeds(ids, r, 3).tolist() == oracle.split_seeds(ids, 3)[r].tolist()
+
+
+def test_cache_fixture(oracle, synth):
+    g = load_golden("cache_fixture")
+    spec = synth.spec_for("products", scale=0.002)
+    ds = synth.generate(spec)
+    V = spec.V
+    assert V == g["V"]
+    rng = np.random.RandomState(7)
+    i = 0
+    for Kg in (1, 2, 4):
+        acc_n = [rng.zipf(1.6, V).astype(np.uint64) % 50 for _ in range(Kg)]
+        acc_e = [rng.zipf(1.5, V).astype(np.uint64) % 40 for _ in range(Kg)]
+        AF, QF = oracle.candidate_selection(acc_n, V)
+        AT, QT = oracle.candidate_selection(acc_e, V)
+        # ranking: hotness descending, ties by ascending id (documented tie rule)
+        tot = sum(a.astype(np.int64) for a in acc_n)
+        order = np.lexsort((np.arange(V), -tot))
+        assert np.array_equal(QF, order.astype(np.int32)) and np.array_equal(AF, tot[order].astype(np.uint64))
+        for budget in (200_000, 1_000_000, 3_000_000):
+            case = g["cases"][i]; i += 1
+            cm = oracle.cost_model(AF, AT, QT, ds.indptr, V, spec.F, budget, Kg, [123456, 654321], [5000] * Kg, 24)
+            assert case["Kg"] == Kg and case["budget"] == budget
+            for k in ("node_capacity", "edge_capacity", "alpha_idx"):
+                assert cm[k] == case[k], (Kg, budget, k)
+            assert abs(cm["best_trans"] - case["best_trans"]) <= 1e-6 * max(1.0, abs(case["best_trans"]))
+            assert sha(QF) == case["QF_sha256"] and sha(QT) == case["QT_sha256"]
+            # capacities respect the budget split: alpha*budget on topology, the rest on features
+            assert (cm["node_capacity"] - 1) * Kg * spec.F * 4 <= budget * Kg
+
+
+def test_placement_rule(oracle):
+    """(rank t, Kg) -> owner t%Kg + Ki*Kg, row t/Kg, global slot (t%Kg)*cap + t/Kg  (GPUCache.cu:88-108)."""
+    import ctypes as C
+    L = oracle.lib()
+    V = 64
+    QF = np.random.RandomState(3).permutation(V).astype(np.int32)
+    for p in load_golden("cache_fixture")["placement"]:
+        t, Kg, Ki, cap = p["t"], p["Kg"], p["Ki"], p["capacity"]
+        assert p["owner"] == t % Kg + Ki * Kg and p["row"] == t // Kg and p["slot"] == (t % Kg) * cap + t // Kg
+    for Kg, cap in ((1, 10), (2, 7), (4, 5), (8, 8)):
+        nm = np.empty(V, np.int32)
+        L.lo_build_feat_map(nm.ctypes.data_as(C.c_void_p), C.c_int32(V), QF.ctypes.data_as(C.c_void_p), C.c_int32(cap), C.c_int32(Kg))
+        own, row = np.empty(V, np.int8), np.empty(V, np.int32)
+        L.lo_build_topo_map(own.ctypes.data_as(C.c_void_p), row.ctypes.data_as(C.c_void_p), C.c_int32(V),
+                            QF.ctypes.data_as(C.c_void_p), C.c_int32(cap), C.c_int32(Kg), C.c_int32(1))
+        n = min(cap * Kg, V)
+        for t in range(V):
+            if t < n:
+                assert nm[QF[t]] == (t % Kg) * cap + t // Kg and own[QF[t]] == t % Kg + Kg and row[QF[t]] == t // Kg
+            else:
+                assert nm[QF[t]] == -1 and own[QF[t]] == -1 and row[QF[t]] == -1
+
+
+def test_cached_batch_equals_uncached(oracle, small_ds):
+    """Cache and backing table hold byte-identical rows / adjacency, so a batch does not depend on the
+    cache state (Kernels.cu:692-699, :391-410)."""
+    ds = small_ds
+    V, F = ds.spec.V, ds.spec.F
+    lab = ds.labels[ds.train]
+    B, fan = 400, [10, 5]
+    base = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, V, F, B, fan).run_batch(ds.train, lab, 0)
+    hot = np.bincount(ds.indices, minlength=V).astype(np.uint64)
+    _, Q = oracle.candidate_selection([hot], V)
+    for Kg, cap in ((1, 900), (2, 700), (4, 300)):
+        r = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, V, F, B, fan, partition_count=Kg)
+        r.set_feature_cache(Q, cap, Kg)
+        r.set_topo_cache(Q, cap, Kg)
+        res = r.run_batch(ds.train, lab, 0)
+        for k in base:
+            assert np.array_equal(base[k], res[k]), (Kg, k)
+        hits = (r.node_map[res["ids"]] >= 0).mean()
+        assert 0.0 < hits < 1.0          # both the hit and the miss path were exercised
+
+
+def test_presampling_hotness(oracle, small_ds):
+    ds = small_ds
+    V, F = ds.spec.V, ds.spec.F
+    lab = ds.labels[ds.train]
+    B, fan = 300, [10, 5]
+    r = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, V, F, B, fan)
+    tot_nodes = tot_edges = 0
+    for it in range(3):
+        res = r.run_batch(ds.train, lab, it, is_presc=True)
+        tot_nodes += int(res["nc"][5 + 2 * len(fan)])
+        tot_edges += int(res["ec"][2 + len(fan)])
+    assert int(r.node_access_time.sum()) == tot_nodes      # HotnessMeasure: +1 per unique node per batch
+    assert int(r.edge_access_time.sum()) == tot_edges      # kernel_pre_sampler: +1 on the source per sampled edge
+    assert (r.position_map[res["ids"]] == 0).all()          # ClearPosMap ran (train mode)
+
+
+def test_synth_generator(synth):
+    spec = synth.spec_for("papers100M", scale=0.0005)
+    ds = synth.generate(spec)
+    assert ds.indptr[0] == 0 and (np.diff(ds.indptr) >= 1).all()
+    assert ds.indices.min() >= 0 and ds.indices.max() < spec.V
+    assert abs(ds.E / spec.V - spec.mean_degree) / spec.mean_degree < 0.15
+    assert len(np.unique(np.concatenate([ds.train, ds.valid, ds.test]))) == len(ds.train) + len(ds.valid) + len(ds.test)
+    assert np.array_equal(ds.features[:7], synth.features(spec, np.arange(7)))
+    assert np.abs(ds.features).max() <= 0.5
+    ind = np.bincount(ds.indices, minlength=spec.V)
+    assert ind.max() > 50 * ind.mean()                      # skewed in-degree: hot nodes exist
+    # determinism
+    assert sha(synth.generate(spec).indices) == sha(ds.indices)
+
+
+def test_legion_file_layout(synth, tmp_path):
+    spec = synth.spec_for("products", scale=0.001)
+    ds = synth.generate(spec)
+    path = str(tmp_path / "ds")
+    synth.write_legion_files(ds, path, partition_count=2)
+    assert os.path.getsize(os.path.join(path, "edge_src")) == (spec.V + 1) * 8
+    assert os.path.getsize(os.path.join(path, "edge_dst")) == ds.E * 4
+    assert os.path.getsize(os.path.join(path, "features")) == spec.V * spec.F * 4
+    assert np.array_equal(np.fromfile(os.path.join(path, "trainingset"), dtype="<i4"), ds.train)
+    line = synth.meta_config_line(ds, path, 8000, 1 << 30, 10, 0).split()
+    assert len(line) == 11 and int(line[2]) == spec.V and int(line[3]) == ds.E and line[0].endswith("/")

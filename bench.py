@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10,5")
     ap.add_argument("--gather", default="all", choices=["all", "level"], help="one gather per batch or one per level")
+    ap.add_argument("--pipeline", default="serial", choices=["overlap", "serial"],
+                    help="overlap: gather of batch i on a second stream while batch i+1 is sampled (depth-2 pipes)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
     return ap.parse_args()
@@ -105,11 +107,14 @@ def main():
     gen_s = time.time() - t0
 
     seeds = dict(train=[((mine.data_ptr(), n_mine), (my_labels.data_ptr(), n_mine))])
+    overlap = args.pipeline == "overlap" and args.gather == "all"
+    depth = 2 if overlap else 1
     eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=1,
-                   csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E)
+                   csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E, pipeline_depth=depth)
     eng.alloc_features()
     L.GPUCache_SetPreSc(eng.cache, 0)  # steady state: no pre-sampling epoch in the all-resident configuration
-    stream = L.d_stream_create()
+    stream = L.d_stream_create()       # sampler stream
+    gstream = L.d_stream_create() if overlap else stream   # gather stream (reference: streams_[1], Server.cu:178-181)
     steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
     K_steps, W = args.steps, args.warmup
 
@@ -117,12 +122,21 @@ def main():
     log = K.DevBuf((K_steps + W) * 128)  # nc/ec of every step, copied on-stream
     ev = [(L.d_event_create(), L.d_event_create()) for _ in range(K_steps)]
     pool = eng.pools[0]
-    o = eng.out[0][0]
+    ev_sampled = [L.d_event_create() for _ in range(depth)]   # sampling of the batch in pipe q is complete
+    ev_gathered = [L.d_event_create() for _ in range(depth)]  # gather of the batch in pipe q is complete
+    used = [False] * depth
 
     def step(i, timed_idx=None):
+        """One mini-batch.  overlap: depth-2 pipes (the reference's PIPELINE_DEPTH), the sampler of batch
+        i+1 runs on `stream` while the gather of batch i runs on `gstream`; a pipe's buffers are reused
+        only after its gather finished."""
         it = i % steps_avail
-        L.GPUMemoryPool_SetCurrentPipe(pool, 0)
+        q = i % depth
+        o = eng.out[0][q]
+        L.GPUMemoryPool_SetCurrentPipe(pool, q)
         L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        if overlap and used[q]:
+            L.d_stream_wait_event(stream, ev_gathered[q])
         L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, it, 0, 0, K.TRAINMODE)
         if per_level:
             L.get_feature_kernel(stream, eng.cache, eng.noder, pool, 0, 1, 1)
@@ -130,31 +144,38 @@ def main():
             L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
             if per_level:
                 L.get_feature_kernel(stream, eng.cache, eng.noder, pool, 0, 2 * h + 3, 1)
-        if not per_level:
-            if timed_idx is not None:
-                L.d_event_record(ev[timed_idx][0], stream)
-            L.get_feature_kernel_all(stream, eng.cache, eng.noder, pool, 0, 1)
-            if timed_idx is not None:
-                L.d_event_record(ev[timed_idx][1], stream)
         L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
         L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
+        if not per_level:
+            if overlap:
+                L.d_event_record(ev_sampled[q], stream)
+                L.d_stream_wait_event(gstream, ev_sampled[q])
+            if timed_idx is not None:
+                L.d_event_record(ev[timed_idx][0], gstream)
+            L.get_feature_kernel_all(gstream, eng.cache, eng.noder, pool, 0, 1)
+            if timed_idx is not None:
+                L.d_event_record(ev[timed_idx][1], gstream)
+            if overlap:
+                L.d_event_record(ev_gathered[q], gstream)
+                used[q] = True
         L.make_update_plan(stream, eng.graph, eng.cache, pool, 0, K.TRAINMODE)
         L.update_cache(stream, eng.cache, eng.noder, pool, 0, K.TRAINMODE)
 
-    def barrier():
+    def drain():
         L.d_stream_sync(stream)
+        if overlap:
+            L.d_stream_sync(gstream)
         torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
 
     for i in range(W):
         step(i)
-    barrier()
+    drain()
+    if world > 1:
+        torch.distributed.barrier()
     t_start = time.perf_counter()
     for i in range(K_steps):
         step(W + i, timed_idx=i)
-    L.d_stream_sync(stream)
-    torch.cuda.synchronize()
+    drain()
     elapsed = time.perf_counter() - t_start
     if world > 1:
         torch.distributed.barrier()
@@ -206,7 +227,7 @@ def main():
             "dtype": "int32 ids / f32 rows (verbatim copy)",
             "data": "synthetic",
             "config": {"workload": f"{spec.name}-shape synthetic graph, {H}-hop fan-out {fan}, batch {B}, CSR + features resident in HBM (Kg=1 replicas)",
-                       "V": V, "E": E, "F": F, "batch": B, "fanout": fan, "gather": args.gather, "seeds_per_rank": n_mine,
+                       "V": V, "E": E, "F": F, "batch": B, "fanout": fan, "gather": args.gather, "pipeline": args.pipeline if args.gather == "all" else "serial", "seeds_per_rank": n_mine,
                        "parallelism": f"dp{world} (seed shards tid % {world}, no data-path collective)"},
             "feature_GBps": round(job_nodes * 4 * F / elapsed_max / 1e9, 2),
             "batches_per_s": round(K_steps * world / elapsed_max, 2),

@@ -79,6 +79,7 @@ void d_memset_async(void* dst, int value, int64_t num_bytes, void* stream);
 void* d_event_create(void);                       /* timing-enabled hipEvent_t */
 void d_event_destroy(void* event);
 void d_event_record(void* event, void* stream);
+void d_stream_wait_event(void* stream, void* event); /* hipStreamWaitEvent */
 float d_event_elapsed_ms(void* start, void* stop); /* synchronises on `stop` */
 
 /* ---- BuildInfo: src/BuildInfo.h:5-70 (the fields the hot path uses; BaM/SSD fields dropped) */
@@ -177,9 +178,10 @@ int32_t* GPUMemoryPool_GetAggSrcId(const GPUMemoryPool* p);
 int32_t* GPUMemoryPool_GetCacheSearchBuffer(const GPUMemoryPool* p);
 char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p);
 int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p);
-/* The dedup/position table (replaces accessed_map + position_map): u32[V],
- * 0xFFFFFFFF = not in the current batch, otherwise the node's index in sampled_ids. */
-uint32_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p);
+/* The dedup/position table (replaces accessed_map + position_map): u64[V],
+ * entry = (epoch << 32) | value with epoch = 0xFFFFFFFF - batch serial; an entry whose epoch is not
+ * the running batch's is "not in the batch"; value < 0x80000000 is the node's index in sampled_ids. */
+uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p);
 void GPUMemoryPool_Finalize(GPUMemoryPool* p);
 void GPUMemoryPool_Delete(GPUMemoryPool* p);
 

@@ -69,6 +69,7 @@ _SIGS = {
     "d_event_create": (vp, []),
     "d_event_destroy": (None, [vp]),
     "d_event_record": (None, [vp, vp]),
+    "d_stream_wait_event": (None, [vp, vp]),
     "d_event_elapsed_ms": (C.c_float, [vp, vp]),
     "SetGPUDevice": (None, [i32]),
     "GetGPUDevice": (i32, []),

@@ -64,8 +64,10 @@ struct SamplerBuffers {
     int32_t* agg_dst_off;   // IPC buffer 4
     int32_t* nc;            // IPC buffer 5
     int32_t* ec;            // IPC buffer 6
-    uint32_t* pos_map;      // u32[V]
+    unsigned long long* pos_map; // u64[V]: (epoch << 32) | value
+    uint32_t epoch;         // 0xFFFFFFFF - batch serial: newer batches compare smaller
     int32_t* cand;          // i32[max slots of a hop]
+    int32_t* aux;           // i32[max slots of a hop]: known final position or -1
     int32_t* tile_edge;     // i32[max tiles]
     int32_t* tile_node;     // i32[max tiles]
     HopState* hop_state;
@@ -73,10 +75,8 @@ struct SamplerBuffers {
 };
 
 void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size, int32_t counter,
-                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, uint32_t* pos_map,
-                 int32_t* nc, int32_t* ec);
-void launch_reset_pos_map(hipStream_t s, uint32_t* pos_map, const int32_t* ids, const int32_t* nc, int32_t hops,
-                          int32_t bound);
+                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
+                 uint32_t epoch, int32_t* nc, int32_t* ec);
 void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers& b, int32_t count, int32_t op_id,
                        int32_t hops, int32_t slots_bound, bool is_presc);
 void launch_find_feat(hipStream_t s, const int32_t* sampled_ids, int32_t* cache_offset, const int32_t* nc,
@@ -133,8 +133,10 @@ struct GPUMemoryPool {
     int32_t fanout[LEGION_MAX_HOPS] = {0};
     int32_t max_slots = 0, max_tiles = 0;
     int32_t feature_rows = 0;         // capacity of the feature buffers in rows (0 = unbounded)
-    uint32_t* pos_map = nullptr;
+    unsigned long long* pos_map = nullptr; // u64[V], see kernels.hip "position table"
+    uint32_t batch_serial = 0;        // batches started on this pool; epoch = 0xFFFFFFFF - serial
     int32_t* cand = nullptr;
+    int32_t* aux = nullptr;
     int32_t* tile_edge = nullptr;
     int32_t* tile_node = nullptr;
     legion::HopState* hop_state = nullptr;
@@ -149,10 +151,6 @@ struct GPUMemoryPool {
     int32_t bound_n = 0;        // upper bound of the next hop's input count
     int32_t bound_nodes = 0;    // upper bound of nodes discovered so far
     int32_t level_bound[LEGION_MAX_HOPS + 1] = {0};
-    // residue of the previous batch that still has to be wiped from pos_map
-    const int32_t* dirty_ids = nullptr;
-    const int32_t* dirty_nc = nullptr;
-    int32_t dirty_bound = 0;
     explicit GPUMemoryPool(int32_t depth);
 };
 

@@ -90,8 +90,8 @@ __device__ inline int32_t total_nodes(const int32_t* nc, int32_t hops) { return 
 __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids, int32_t* __restrict__ labels,
                                                  int32_t size, int32_t counter, const int32_t* __restrict__ all_ids,
                                                  const int32_t* __restrict__ all_labels, int32_t total_cap,
-                                                 uint32_t* __restrict__ pos_map, int32_t* __restrict__ nc,
-                                                 int32_t* __restrict__ ec)
+                                                 unsigned long long* __restrict__ pos_map, uint32_t epoch,
+                                                 int32_t* __restrict__ nc, int32_t* __restrict__ ec)
 {
     int32_t idx = threadIdx.x + blockDim.x * blockIdx.x;
     if (idx < size) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
         } else {
             int32_t src_id = all_ids[g % total_cap];
             batch_ids[idx] = src_id;
-            pos_map[src_id] = (uint32_t)idx;
+            pos_map[src_id] = ((unsigned long long)epoch << 32) | (uint32_t)idx;
             labels[idx] = all_labels[g % total_cap];
         }
     }
@@ -114,19 +114,8 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
     }
 }
 
-// S7: ClearPosMap (Kernels.cu:750-756) -- wipe the table over the batch's own ids
-__global__ __launch_bounds__(kBlock) void k_reset_pos_map(uint32_t* __restrict__ pos_map,
-                                                          const int32_t* __restrict__ ids,
-                                                          const int32_t* __restrict__ nc, int32_t hops)
-{
-    // nc[0] is the append cursor: == nc[5+2H] (nc[9] at H=2) once the last hop ran, and still
-    // right when a batch was abandoned after fewer hops.
-    const int32_t n = nc[0];
-    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        int32_t id = ids[i];
-        if (id >= 0) pos_map[id] = kUnseen;
-    }
-}
+// S7: ClearPosMap (Kernels.cu:750-756) has no kernel here: position-table entries carry the batch epoch
+// in their upper 32 bits, so entries of older batches are simply stale (see the table format below).
 
 // ------------------------------------------------------------------------------------------------
 // S3: sampler, pass 1 -- draw + claim
@@ -137,10 +126,11 @@ struct SampleArgs {
     const int32_t* agg_src_ids;
     const int32_t* nc;
     const int32_t* ec;
-    uint32_t* pos_map;
+    unsigned long long* pos_map;
     int32_t* cand;
     int32_t* tile_edge;
     unsigned long long* edge_access_time;
+    uint32_t epoch;
     const uint32_t* pow_tab;   // pow_tab[m] = 48271^(m+1), m < kTile
     uint32_t a_tile;           // 48271^kTile
     uint32_t a_step;           // 48271^(kTile * gridDim.x)
@@ -225,8 +215,9 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                     if (dst >= 0) {
                         if (PRESC) atomicAdd(a.edge_access_time + s_src[r], 1ull); // Kernels.cu:525
                         // claim: lowest idx wins.  A stale (larger) read only costs a redundant atomic.
-                        const uint32_t mine = kProvisional | (uint32_t)idx;
-                        const uint32_t cur = a.pos_map[dst];
+                        // Entries of older batches have a larger epoch field, i.e. compare greater: unseen.
+                        const unsigned long long mine = ((unsigned long long)a.epoch << 32) | kProvisional | (uint32_t)idx;
+                        const unsigned long long cur = a.pos_map[dst];
                         if (cur > mine) atomicMin(a.pos_map + dst, mine);
                         cnt++;
                     } else {
@@ -255,8 +246,12 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // ------------------------------------------------------------------------------------------------
 // S3 pass 2 -- flag the winners (bit 31 of cand), count new nodes per tile
 // ------------------------------------------------------------------------------------------------
+// aux[idx] = the neighbour's final position when it is already known here (node seen in an earlier
+// hop / seed), else -1; k_write turns that into the src-side COO offset so that k_resolve only has to
+// probe the table for edges that lost the claim to another slot of the same hop.
 __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, int32_t count,
-                                                 const uint32_t* __restrict__ pos_map, int32_t* __restrict__ cand,
+                                                 const unsigned long long* __restrict__ pos_map, uint32_t epoch,
+                                                 int32_t* __restrict__ cand, int32_t* __restrict__ aux,
                                                  int32_t* __restrict__ tile_node)
 {
     __shared__ int32_t s_cnt[kBlock / 64];
@@ -265,21 +260,29 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int32_t cnt = 0;
         int32_t c[kTile / kBlock];
-        uint32_t v[kTile / kBlock];
+        unsigned long long v[kTile / kBlock];
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
             c[s] = (idx < total) ? cand[idx] : -1;
         }
 #pragma unroll
-        for (int s = 0; s < kTile / kBlock; s++) v[s] = (c[s] >= 0) ? pos_map[c[s]] : 0u;
+        for (int s = 0; s < kTile / kBlock; s++) v[s] = (c[s] >= 0) ? pos_map[c[s]] : 0ull;
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            if (c[s] >= 0 && v[s] == (kProvisional | (uint32_t)idx)) {
-                cand[idx] = (int32_t)((uint32_t)c[s] | 0x80000000u);
-                cnt++;
+            if (idx >= total) continue;
+            int32_t known = -1;
+            if (c[s] >= 0) {
+                const uint32_t lo = (uint32_t)v[s]; // the epoch field equals ours: k_sample claimed every live dst
+                if (lo == (kProvisional | (uint32_t)idx)) {
+                    cand[idx] = (int32_t)((uint32_t)c[s] | 0x80000000u);
+                    cnt++;
+                } else if (lo < kProvisional) {
+                    known = (int32_t)lo;
+                }
             }
+            aux[idx] = known;
         }
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
         if (lane_id() == 0) s_cnt[wave_id()] = cnt;
@@ -357,15 +360,17 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(int32_t* __restrict__
 struct WriteArgs {
     const HopState* hs;
     const int32_t* cand;
+    const int32_t* aux;
     const int32_t* tile_edge;
     const int32_t* tile_node;
     int32_t* sampled_ids;
     int32_t* agg_src_ids;
     int32_t* agg_src_off;
     int32_t* agg_dst_off;
-    uint32_t* pos_map;
+    unsigned long long* pos_map;
     FastDiv fdiv;
     int32_t op_id;
+    uint32_t epoch;
 };
 
 __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
@@ -413,11 +418,14 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             // (construct_graph, Kernels.cu:457-461) without the random read.
             const int32_t i = (int32_t)fdiv((uint32_t)idx, a.fdiv);
             a.agg_dst_off[e] = (a.op_id == 2) ? i : a.agg_src_off[h.in_off + i];
+            int32_t so = a.aux[idx]; // known position, or -1: resolved by k_resolve once every winner has written
             if (c[s] < 0) {
                 const int32_t p = nbase + pn + rn[s];
                 a.sampled_ids[p] = dst;
-                a.pos_map[dst] = (uint32_t)p;
+                a.pos_map[dst] = ((unsigned long long)a.epoch << 32) | (uint32_t)p;
+                so = p;
             }
+            a.agg_src_off[e] = so;
         }
         __syncthreads();
     }
@@ -426,12 +434,12 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
 // S4 (src side): agg_src_off[e] = position of the sampled neighbour (construct_graph, Kernels.cu:456-460)
 __global__ __launch_bounds__(kBlock) void k_resolve(const HopState* __restrict__ hs,
                                                     const int32_t* __restrict__ agg_src_ids,
-                                                    const uint32_t* __restrict__ pos_map,
+                                                    const unsigned long long* __restrict__ pos_map,
                                                     int32_t* __restrict__ agg_src_off)
 {
     const int32_t base = hs->edge_base, n = hs->n_edges;
     for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x)
-        agg_src_off[base + i] = (int32_t)pos_map[agg_src_ids[base + i]];
+        if (agg_src_off[base + i] < 0) agg_src_off[base + i] = (int32_t)(uint32_t)pos_map[agg_src_ids[base + i]];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -670,18 +678,11 @@ static uint32_t* pow_table()
 }
 
 void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size, int32_t counter,
-                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, uint32_t* pos_map,
-                 int32_t* nc, int32_t* ec)
+                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
+                 uint32_t epoch, int32_t* nc, int32_t* ec)
 {
     int blocks = size > 0 ? (size - 1) / kBlock + 1 : 1;
-    k_seed<<<blocks, kBlock, 0, s>>>(batch_ids, labels, size, counter, all_ids, all_labels, total_cap, pos_map, nc, ec);
-    HIP_CHECK_LAST();
-}
-
-void launch_reset_pos_map(hipStream_t s, uint32_t* pos_map, const int32_t* ids, const int32_t* nc, int32_t hops,
-                          int32_t bound)
-{
-    k_reset_pos_map<<<grid_for(bound, kBlock), kBlock, 0, s>>>(pos_map, ids, nc, hops);
+    k_seed<<<blocks, kBlock, 0, s>>>(batch_ids, labels, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, nc, ec);
     HIP_CHECK_LAST();
 }
 
@@ -696,6 +697,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     a.sampled_ids = b.sampled_ids; a.agg_src_ids = b.agg_src_ids; a.nc = b.nc; a.ec = b.ec;
     a.pos_map = b.pos_map; a.cand = b.cand; a.tile_edge = b.tile_edge;
     a.edge_access_time = b.edge_access_time;
+    a.epoch = b.epoch;
     a.pow_tab = pow_table();
     a.a_tile = powmod31(kA, kTile);
     a.a_step = powmod31(kA, (uint64_t)kTile * (uint64_t)grid);
@@ -706,12 +708,12 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
     else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
-    k_mark<<<grid, kBlock, 0, s>>>(b.nc, count, b.pos_map, b.cand, b.tile_node);
+    k_mark<<<grid, kBlock, 0, s>>>(b.nc, count, b.pos_map, b.epoch, b.cand, b.aux, b.tile_node);
     HIP_CHECK_LAST();
     k_scan_tiles<<<1, kScanBlock, 0, s>>>(b.nc, b.ec, count, op_id, hops, b.tile_edge, b.tile_node, b.hop_state);
     HIP_CHECK_LAST();
     WriteArgs w;
-    w.hs = b.hop_state; w.cand = b.cand; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
+    w.hs = b.hop_state; w.cand = b.cand; w.aux = b.aux; w.epoch = b.epoch; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
     w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
     w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id;
     k_write<<<grid, kBlock, 0, s>>>(w);

@@ -58,22 +58,21 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
 
     GPUMemoryPool* p = memorypool;
     p->device_id = dev_id;
-    // ClearPosMap of a batch whose planner op never ran (any mode)
-    if (p->dirty_ids) {
-        launch_reset_pos_map(s, p->pos_map, p->dirty_ids, p->dirty_nc, p->hops, p->dirty_bound);
-        p->dirty_ids = nullptr;
+    // A new batch = a new epoch of the position table: entries of older batches become stale without
+    // touching them (replaces cudaMemsetAsync(accessed_map) + ClearPosMap, Kernels.cu:216,750-756).
+    if (++p->batch_serial >= 0xFFFFFFF0u) { // epoch space exhausted: wipe once and start over
+        HIP_CHECK(hipMemsetAsync(p->pos_map, 0xFF, (size_t)p->V * sizeof(unsigned long long), s));
+        p->batch_serial = 1;
     }
+    const uint32_t epoch = 0xFFFFFFFFu - p->batch_serial;
     // Kernels.cu:224
     int32_t size = ((batch_size * (counter + 1)) >= total_cap) ? (total_cap - batch_size * counter) : batch_size;
     if (size > p->batch_size) { LEGION_ARG_ERROR("batch_generator_kernel: batch larger than the pool was sized for"); return; }
     const int q = p->current_pipe;
-    launch_seed(s, p->sampled_ids[q], p->labels[q], size, counter, all_ids, all_labels, total_cap, p->pos_map,
+    launch_seed(s, p->sampled_ids[q], p->labels[q], size, counter, all_ids, all_labels, total_cap, p->pos_map, epoch,
                 p->node_counter[q], p->edge_counter[q]);
     p->bound_n = size > 0 ? size : 0;
     p->bound_nodes = p->bound_n;
-    p->dirty_ids = p->sampled_ids[q];
-    p->dirty_nc = p->node_counter[q];
-    p->dirty_bound = p->num_ids;
 }
 
 // GPU_Random_Sampling, Kernels.cu:567-659
@@ -103,7 +102,7 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     const int q = p->current_pipe;
     b.sampled_ids = p->sampled_ids[q]; b.agg_src_ids = p->agg_src_ids; b.agg_src_off = p->agg_src_off[q];
     b.agg_dst_off = p->agg_dst_off[q]; b.nc = p->node_counter[q]; b.ec = p->edge_counter[q];
-    b.pos_map = p->pos_map; b.cand = p->cand; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
+    b.pos_map = p->pos_map; b.epoch = 0xFFFFFFFFu - p->batch_serial; b.cand = p->cand; b.aux = p->aux; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
     b.hop_state = p->hop_state; b.edge_access_time = nullptr;
     if (is_presc) {
         // kernel_pre_sampler_optimized: host CSR only + topology hotness (Kernels.cu:636-649)
@@ -183,10 +182,8 @@ void make_update_plan(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache, G
     hipStream_t s = (hipStream_t)strm_hdl;
     if (mode == LEGION_TRAINMODE && cache) // CacheProfiling: HotnessMeasure during pre-sampling
         GPUCache_CacheProfiling(cache, p->sampled_ids[q], p->node_counter[q], strm_hdl, dev_id);
-    // ClearPosMap.  The reference clears in train mode only because its bitmap guards stale
-    // entries; our single table must be clean before the next batch in every mode.
-    launch_reset_pos_map(s, p->pos_map, p->sampled_ids[q], p->node_counter[q], p->hops, p->num_ids);
-    if (p->dirty_ids == p->sampled_ids[q]) p->dirty_ids = nullptr;
+    // ClearPosMap (Kernels.cu:780) needs no launch: the next batch starts a new table epoch.
+    (void)s;
 }
 
 // update_cache, Kernels.cu:785-805: the reference body is commented out -- a no-op.

@@ -138,6 +138,7 @@ void* d_event_create(void)
 }
 void d_event_destroy(void* event) { (void)hipEventDestroy((hipEvent_t)event); }
 void d_event_record(void* event, void* stream) { HIP_CHECK(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); }
+void d_stream_wait_event(void* stream, void* event) { HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0)); }
 float d_event_elapsed_ms(void* start, void* stop)
 {
     float ms = 0.f;

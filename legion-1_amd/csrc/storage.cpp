@@ -262,9 +262,11 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     p->max_slots = (int32_t)max_slots;
     p->max_tiles = (int32_t)((max_slots + kTile - 1) / kTile);
     p->owns_scratch = true;
-    HIP_CHECK(hipMalloc(&p->pos_map, (size_t)total_num_nodes * sizeof(uint32_t)));
-    HIP_CHECK(hipMemset(p->pos_map, 0xFF, (size_t)total_num_nodes * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc(&p->pos_map, (size_t)total_num_nodes * sizeof(unsigned long long)));
+    HIP_CHECK(hipMemset(p->pos_map, 0xFF, (size_t)total_num_nodes * sizeof(unsigned long long)));
+    p->batch_serial = 0;
     HIP_CHECK(hipMalloc(&p->cand, (size_t)p->max_slots * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&p->aux, (size_t)p->max_slots * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_edge, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_node, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->hop_state, sizeof(HopState)));
@@ -299,12 +301,12 @@ int32_t* GPUMemoryPool_GetAggSrcId(const GPUMemoryPool* p) { return p->agg_src_i
 int32_t* GPUMemoryPool_GetCacheSearchBuffer(const GPUMemoryPool* p) { return p->cache_search_buffer; }
 char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p) { return (char*)p->tmp_part_ind; }
 int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p) { return p->tmp_part_off; }
-uint32_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p) { return p->pos_map; }
+uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p) { return (uint64_t*)p->pos_map; }
 
 void GPUMemoryPool_Finalize(GPUMemoryPool* p)
 {
     if (!p || !p->owns_scratch) return;
-    (void)hipFree(p->pos_map); (void)hipFree(p->cand); (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
+    (void)hipFree(p->pos_map); (void)hipFree(p->cand); (void)hipFree(p->aux); p->aux = nullptr; (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
     (void)hipFree(p->hop_state); (void)hipFree(p->cache_search_buffer); (void)hipFree(p->agg_src_ids);
     (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off);
     p->pos_map = nullptr; p->cand = nullptr; p->tile_edge = p->tile_node = nullptr; p->hop_state = nullptr;

@@ -128,6 +128,7 @@ struct SampleArgs {
     const int32_t* ec;
     unsigned long long* pos_map;
     int32_t* cand;
+    int32_t* aux;
     int32_t* tile_edge;
     unsigned long long* edge_access_time;
     uint32_t epoch;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile_start + tid + kBlock * s;
-            int32_t dst = -1;
+            int32_t dst = -1, known = -1;
             if (idx < tile_end) {
                 const uint32_t i = fdiv((uint32_t)idx, a.fdiv);
                 const int32_t j = idx - (int32_t)i * f;
@@ -219,12 +220,16 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                         const unsigned long long mine = ((unsigned long long)a.epoch << 32) | kProvisional | (uint32_t)idx;
                         const unsigned long long cur = a.pos_map[dst];
                         if (cur > mine) atomicMin(a.pos_map + dst, mine);
+                        // final positions are only written by earlier launches: if we see one it is exact,
+                        // and k_mark need not probe the table for this slot again
+                        if (cur < (((unsigned long long)a.epoch << 32) | kProvisional)) known = (int32_t)(uint32_t)cur;
                         cnt++;
                     } else {
                         dst = -1;
                     }
                 }
                 a.cand[idx] = dst;
+                a.aux[idx] = known;
             }
         }
         // tile edge count
@@ -246,9 +251,9 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // ------------------------------------------------------------------------------------------------
 // S3 pass 2 -- flag the winners (bit 31 of cand), count new nodes per tile
 // ------------------------------------------------------------------------------------------------
-// aux[idx] = the neighbour's final position when it is already known here (node seen in an earlier
-// hop / seed), else -1; k_write turns that into the src-side COO offset so that k_resolve only has to
-// probe the table for edges that lost the claim to another slot of the same hop.
+// aux[idx] (written by k_sample) = the neighbour's final position when it was already known (node seen in
+// an earlier hop / seed), else -1.  Only the other slots probe the table here: a slot whose claim
+// survived is the winner of a new node.
 __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, int32_t count,
                                                  const unsigned long long* __restrict__ pos_map, uint32_t epoch,
                                                  int32_t* __restrict__ cand, int32_t* __restrict__ aux,
@@ -264,25 +269,24 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            c[s] = (idx < total) ? cand[idx] : -1;
+            c[s] = -1;
+            if (idx < total && aux[idx] < 0) c[s] = cand[idx];
         }
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) v[s] = (c[s] >= 0) ? pos_map[c[s]] : 0ull;
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            if (idx >= total) continue;
-            int32_t known = -1;
-            if (c[s] >= 0) {
-                const uint32_t lo = (uint32_t)v[s]; // the epoch field equals ours: k_sample claimed every live dst
-                if (lo == (kProvisional | (uint32_t)idx)) {
-                    cand[idx] = (int32_t)((uint32_t)c[s] | 0x80000000u);
-                    cnt++;
-                } else if (lo < kProvisional) {
-                    known = (int32_t)lo;
-                }
+            if (c[s] < 0) continue;
+            const uint32_t lo = (uint32_t)v[s];
+            if (lo == (kProvisional | (uint32_t)idx)) {
+                cand[idx] = (int32_t)((uint32_t)c[s] | 0x80000000u);
+                cnt++;
+            } else {
+                // lost the claim: the table names the winning slot of this hop (all claims are final once
+                // k_sample has finished).  Stash it: k_resolve then needs no table probe at all.
+                aux[idx] = -2 - (int32_t)(lo & 0x7FFFFFFFu);
             }
-            aux[idx] = known;
         }
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
         if (lane_id() == 0) s_cnt[wave_id()] = cnt;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tiles(int32_t* __restrict__
 struct WriteArgs {
     const HopState* hs;
     const int32_t* cand;
-    const int32_t* aux;
+    int32_t* aux;
     const int32_t* tile_edge;
     const int32_t* tile_node;
     int32_t* sampled_ids;
@@ -371,6 +375,7 @@ struct WriteArgs {
     FastDiv fdiv;
     int32_t op_id;
     uint32_t epoch;
+    int32_t last_hop; // positions of the nodes found in the last hop are never looked up through the table
 };
 
 __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
@@ -418,11 +423,14 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             // (construct_graph, Kernels.cu:457-461) without the random read.
             const int32_t i = (int32_t)fdiv((uint32_t)idx, a.fdiv);
             a.agg_dst_off[e] = (a.op_id == 2) ? i : a.agg_src_off[h.in_off + i];
-            int32_t so = a.aux[idx]; // known position, or -1: resolved by k_resolve once every winner has written
+            int32_t so = a.aux[idx]; // known position (>= 0) or -2 - <winning slot> (k_resolve reads that slot's aux)
             if (c[s] < 0) {
                 const int32_t p = nbase + pn + rn[s];
                 a.sampled_ids[p] = dst;
-                a.pos_map[dst] = ((unsigned long long)a.epoch << 32) | (uint32_t)p;
+                // the winner publishes its position per SLOT (streamed store); the scattered table store
+                // is only needed when a later hop may look the node up by id
+                a.aux[idx] = p;
+                if (!a.last_hop) a.pos_map[dst] = ((unsigned long long)a.epoch << 32) | (uint32_t)p;
                 so = p;
             }
             a.agg_src_off[e] = so;
@@ -431,15 +439,17 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
     }
 }
 
-// S4 (src side): agg_src_off[e] = position of the sampled neighbour (construct_graph, Kernels.cu:456-460)
-__global__ __launch_bounds__(kBlock) void k_resolve(const HopState* __restrict__ hs,
-                                                    const int32_t* __restrict__ agg_src_ids,
-                                                    const unsigned long long* __restrict__ pos_map,
+// S4 (src side): agg_src_off[e] = position of the sampled neighbour (construct_graph, Kernels.cu:456-460).
+// k_write already stored it for known nodes and winners; an edge that lost its claim carries
+// -2 - <winning slot>, and that slot's aux now holds the winner's position.
+__global__ __launch_bounds__(kBlock) void k_resolve(const HopState* __restrict__ hs, const int32_t* __restrict__ aux,
                                                     int32_t* __restrict__ agg_src_off)
 {
     const int32_t base = hs->edge_base, n = hs->n_edges;
-    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x)
-        if (agg_src_off[base + i] < 0) agg_src_off[base + i] = (int32_t)(uint32_t)pos_map[agg_src_ids[base + i]];
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int32_t so = agg_src_off[base + i];
+        if (so < -1) agg_src_off[base + i] = aux[-2 - so];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,7 +490,9 @@ struct GatherKArgs {
     FastDiv div_cap; // / cache_capacity
 };
 
-template <typename VT, int UNROLL>
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <typename VT, int UNROLL, int NT>
 __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
 {
     constexpr int VEC = sizeof(VT) / 4;
@@ -518,10 +530,13 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
-            if (src[u]) val[u] = *src[u];
+            if (src[u]) val[u] = (NT >= 2) ? __builtin_nontemporal_load(src[u]) : *src[u];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++)
-            if (src[u]) reinterpret_cast<VT*>(g.dst)[dsti[u]] = val[u];
+            if (src[u]) {
+                if (NT >= 1) __builtin_nontemporal_store(val[u], reinterpret_cast<VT*>(g.dst) + dsti[u]);
+                else reinterpret_cast<VT*>(g.dst)[dsti[u]] = val[u];
+            }
     }
 }
 
@@ -695,7 +710,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     SampleArgs a;
     a.csr = csr;
     a.sampled_ids = b.sampled_ids; a.agg_src_ids = b.agg_src_ids; a.nc = b.nc; a.ec = b.ec;
-    a.pos_map = b.pos_map; a.cand = b.cand; a.tile_edge = b.tile_edge;
+    a.pos_map = b.pos_map; a.cand = b.cand; a.aux = b.aux; a.tile_edge = b.tile_edge;
     a.edge_access_time = b.edge_access_time;
     a.epoch = b.epoch;
     a.pow_tab = pow_table();
@@ -715,10 +730,10 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     WriteArgs w;
     w.hs = b.hop_state; w.cand = b.cand; w.aux = b.aux; w.epoch = b.epoch; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
     w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
-    w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id;
+    w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id; w.last_hop = (op_id / 2 == hops) ? 1 : 0;
     k_write<<<grid, kBlock, 0, s>>>(w);
     HIP_CHECK_LAST();
-    k_resolve<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.hop_state, b.agg_src_ids, b.pos_map, b.agg_src_off);
+    k_resolve<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.hop_state, b.aux, b.agg_src_off);
     HIP_CHECK_LAST();
 }
 
@@ -750,10 +765,12 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     const int C = vec4 ? g.F / 4 : g.F;
     if ((int64_t)rows_bound * C >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);
-    constexpr int U = 4;
+    // Tuned on MI355X (profiles/r01_gather_sweep.md): 2 chunks in flight per lane, non-temporal loads and
+    // stores (rows are read once and written once: keep them out of L2/MALL), 8 workgroups per CU.
+    constexpr int U = 2;
     const int grid = grid_for((int64_t)rows_bound * C, kBlock * U, 8);
-    if (vec4) k_gather<float4, U><<<grid, kBlock, 0, s>>>(a);
-    else k_gather<float, U><<<grid, kBlock, 0, s>>>(a);
+    if (vec4) k_gather<v4f, U, 2><<<grid, kBlock, 0, s>>>(a);
+    else k_gather<float, U, 2><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
 }
 

@@ -2,8 +2,8 @@
 //
 // Reference semantics restated (liayan/Legion-1, src/):
 //   S1 batch_generator                Kernels.cu:68-96      -> k_seed
-//   S2 update_counter                 Kernels.cu:112-150    -> folded into k_seed / k_scan_tiles
-//   S3 kernel_random_sampler_2        Kernels.cu:342-448    -> k_sample + k_mark + k_scan_tiles + k_write
+//   S2 update_counter                 Kernels.cu:112-150    -> folded into k_seed / k_write (last tile)
+//   S3 kernel_random_sampler_2        Kernels.cu:342-448    -> k_sample + k_mark + k_write
 //   S3' kernel_pre_sampler_optimized  Kernels.cu:468-564    -> k_sample<PRESC>
 //   S4 construct_graph                Kernels.cu:450-463    -> k_write (dst side) + k_resolve (src side)
 //   S5 zero_copy_with_aggregated_cache Kernels.cu:662-702   -> k_gather
@@ -14,16 +14,21 @@
 //  * The reference's output ORDER depends on LDS/global atomicAdd races.  We produce the
 //    canonical schedule (serial, slot-index ascending) deterministically: a hop is
 //      k_sample : every slot draws its neighbour (same Thrust minstd arithmetic), parks it in
-//                 cand[idx] and claims the node with atomicMin(pos_map[dst], PROVISIONAL|idx),
-//                 so the LOWEST slot that touches a new node wins -- exactly the serial order;
-//      k_mark   : the winner of each new node is flagged, per-tile edge/node counts are known;
-//      k_scan   : one workgroup prefix-sums the tile counts and applies update_counter (S2);
-//      k_write  : ordered compaction (wave ballot + popcount prefix, one LDS exchange per tile)
-//                 appends edges / new nodes at their canonical positions;
-//      k_resolve: src-side COO offsets through the now final position table.
-//  * One u32[V] table replaces accessed_map (bitmap) + position_map: 0xFFFFFFFF = unseen,
-//    0x80000000|idx = claimed this hop, else final index in sampled_ids.  No V/8-byte memset per
-//    batch; the table is wiped by scattering over the batch's own ids (ClearPosMap's job).
+//                 cand[idx] and claims the node with atomicMin(pos[dst], PROVISIONAL|idx), so the
+//                 LOWEST slot that touches a new node wins -- exactly the serial order; a neighbour
+//                 whose final position is already in the table is recorded in aux[idx];
+//      k_mark   : the winner of each new node is flagged (its claim survived), a loser records the
+//                 winning slot; per-tile edge / new-node counts are now known;
+//      k_write  : every workgroup sums the tile counts in front of its tile (no scan launch), then
+//                 ordered compaction (wave ballot + popcount prefix, one LDS exchange per tile)
+//                 appends edges / new nodes at their canonical positions and the COO offsets; the
+//                 workgroup of the last tile applies update_counter (S2);
+//      k_resolve: src-side COO offsets of the edges that lost their claim, from the winner's slot.
+//  * One u64[V] "position table" replaces accessed_map (bitmap) + position_map.  Entry =
+//    (epoch << 32) | value, epoch = 0xFFFFFFFF - batch serial, so entries of older batches compare
+//    GREATER than anything of the running batch: they are stale without ever being cleared (no
+//    V/8-byte memset, no ClearPosMap scatter).  value: 0x80000000|idx = claimed in the running hop,
+//    else the final index in sampled_ids.
 //  * Row descriptors (start, degree) of a tile are fetched once per source row and staged in
 //    LDS -- the reference re-reads both int64 indptr words in each of the `count` lanes.
 //  * RNG: x = 48271^(idx+1) mod (2^31-1).  Per thread: one table lookup and one Mersenne
@@ -254,14 +259,22 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // aux[idx] (written by k_sample) = the neighbour's final position when it was already known (node seen in
 // an earlier hop / seed), else -1.  Only the other slots probe the table here: a slot whose claim
 // survived is the winner of a new node.
-__global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, int32_t count,
-                                                 const unsigned long long* __restrict__ pos_map, uint32_t epoch,
-                                                 int32_t* __restrict__ cand, int32_t* __restrict__ aux,
-                                                 int32_t* __restrict__ tile_node)
+__global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, const int32_t* __restrict__ ec,
+                                                 int32_t count, const unsigned long long* __restrict__ pos_map,
+                                                 uint32_t epoch, int32_t* __restrict__ cand, int32_t* __restrict__ aux,
+                                                 int32_t* __restrict__ tile_node, HopState* __restrict__ hs)
 {
     __shared__ int32_t s_cnt[kBlock / 64];
     const int32_t total = nc[2] * count;
     const int32_t n_tiles = (total + kTile - 1) / kTile;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // hop-start snapshot of the counters: k_write's last tile applies update_counter in place, so
+        // its other workgroups must not read the live nc/ec
+        HopState h;
+        h.edge_base = ec[0]; h.node_base = nc[0]; h.n_edges = 0; h.n_nodes = 0;
+        h.in_off = ec[2]; h.n_in = nc[2]; h.slots = total; h.pad = 0;
+        *hs = h;
+    }
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int32_t cnt = 0;
         int32_t c[kTile / kBlock];
@@ -302,67 +315,32 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
 }
 
 // ------------------------------------------------------------------------------------------------
-// S3 pass 3 -- exclusive scan of the tile counts (one workgroup) + update_counter (S2)
+// S2: update_counter (Kernels.cu:128-149), H-hop layout: nc[1] == n_nodes, ec[1] == n_edges of this hop
 // ------------------------------------------------------------------------------------------------
-constexpr int kScanBlock = 1024;
-__global__ __launch_bounds__(kScanBlock) void k_scan_tiles(int32_t* __restrict__ nc, int32_t* __restrict__ ec,
-                                                          int32_t count, int32_t op_id, int32_t hops,
-                                                          int32_t* __restrict__ tile_edge,
-                                                          int32_t* __restrict__ tile_node,
-                                                          HopState* __restrict__ hs)
+__device__ inline void apply_update_counter(int32_t* nc, int32_t* ec, int32_t op_id, int32_t hops, int32_t n_nodes,
+                                            int32_t n_edges)
 {
-    __shared__ int32_t s_e[kScanBlock];
-    __shared__ int32_t s_n[kScanBlock];
-    const int32_t N = nc[2];
-    const int32_t total = N * count;
-    const int32_t n_tiles = (total + kTile - 1) / kTile;
-    const int tid = threadIdx.x;
-    const int32_t per = (n_tiles + kScanBlock - 1) / kScanBlock;
-    const int32_t lo = min(tid * per, n_tiles), hi = min(lo + per, n_tiles);
-    int32_t se = 0, sn = 0;
-    for (int32_t t = lo; t < hi; t++) { se += tile_edge[t]; sn += tile_node[t]; }
-    s_e[tid] = se; s_n[tid] = sn;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (int o = 1; o < kScanBlock; o <<= 1) {
-        int32_t ae = 0, an = 0;
-        if (tid >= o) { ae = s_e[tid - o]; an = s_n[tid - o]; }
-        __syncthreads();
-        s_e[tid] += ae; s_n[tid] += an;
-        __syncthreads();
-    }
-    int32_t be = s_e[tid] - se, bn = s_n[tid] - sn; // exclusive base of this thread's chunk
-    for (int32_t t = lo; t < hi; t++) {
-        int32_t e = tile_edge[t], n = tile_node[t];
-        tile_edge[t] = be; tile_node[t] = bn;
-        be += e; bn += n;
-    }
-    if (tid == kScanBlock - 1) {
-        const int32_t n_edges = s_e[tid], n_nodes = s_n[tid];
-        HopState h;
-        h.edge_base = ec[0]; h.node_base = nc[0]; h.n_edges = n_edges; h.n_nodes = n_nodes;
-        h.in_off = ec[2]; h.n_in = N; h.slots = total; h.pad = 0;
-        *hs = h;
-        // update_counter (Kernels.cu:128-149), H-hop layout: nc[1] == n_nodes, ec[1] == n_edges
-        const int32_t hh = op_id / 2;
-        nc[0] += n_nodes;
-        nc[3 + 2 * hh] = nc[1 + 2 * hh] + nc[2 + 2 * hh];
-        nc[4 + 2 * hh] = n_nodes;
-        if (hh == hops) nc[5 + 2 * hh] = nc[3 + 2 * hh] + nc[4 + 2 * hh];
-        nc[1] = 0;
-        nc[2] = n_edges;
-        ec[2 + hh] = (hh == 1 ? ec[3] : ec[1 + hh]) + n_edges;
-        ec[2] = ec[0];
-        ec[0] += n_edges;
-        ec[1] = 0;
-    }
+    const int32_t hh = op_id / 2;
+    nc[0] += n_nodes;
+    nc[3 + 2 * hh] = nc[1 + 2 * hh] + nc[2 + 2 * hh];
+    nc[4 + 2 * hh] = n_nodes;
+    if (hh == hops) nc[5 + 2 * hh] = nc[3 + 2 * hh] + nc[4 + 2 * hh];
+    nc[1] = 0;
+    nc[2] = n_edges;
+    ec[2 + hh] = (hh == 1 ? ec[3] : ec[1 + hh]) + n_edges;
+    ec[2] = ec[0];
+    ec[0] += n_edges;
+    ec[1] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // S3 pass 4 -- ordered compaction: edges, new nodes, dst-side COO offsets
 // ------------------------------------------------------------------------------------------------
 struct WriteArgs {
-    const HopState* hs;
+    HopState* hs;
+    int32_t* nc;
+    int32_t* ec;
+    int32_t hops;
     const int32_t* cand;
     int32_t* aux;
     const int32_t* tile_edge;
@@ -383,13 +361,24 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
     constexpr int S = kTile / kBlock, W = kBlock / 64;
     __shared__ int32_t s_e[S * W];
     __shared__ int32_t s_n[S * W];
+    __shared__ int32_t s_pre[2][W];
     const HopState h = *a.hs;
     const int32_t total = h.slots;
     const int32_t n_tiles = (total + kTile - 1) / kTile;
     const int lane = lane_id(), wave = wave_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
+    if (n_tiles == 0) { // empty hop: only the counters move
+        if (blockIdx.x == 0 && threadIdx.x == 0) apply_update_counter(a.nc, a.ec, a.op_id, a.hops, 0, 0);
+        return;
+    }
 
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // exclusive prefix of the tile counts: every workgroup sums the (L2-resident, <= 12 k entries)
+        // count arrays in front of its tile itself -- no scan launch, no inter-workgroup hand-off
+        int32_t pre_e = 0, pre_n = 0;
+        for (int32_t t = threadIdx.x; t < tile; t += kBlock) { pre_e += a.tile_edge[t]; pre_n += a.tile_node[t]; }
+        for (int o = 32; o > 0; o >>= 1) { pre_e += __shfl_xor(pre_e, o); pre_n += __shfl_xor(pre_n, o); }
+        if (lane == 0) { s_pre[0][wave] = pre_e; s_pre[1][wave] = pre_n; }
         int32_t c[S], re[S], rn[S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
@@ -406,8 +395,17 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             if (lane == 0) { s_e[s * W + wave] = __popcll(be); s_n[s * W + wave] = __popcll(bn); }
         }
         __syncthreads();
-        const int32_t ebase = h.edge_base + a.tile_edge[tile];
-        const int32_t nbase = h.node_base + a.tile_node[tile];
+        pre_e = 0; pre_n = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) { pre_e += s_pre[0][w]; pre_n += s_pre[1][w]; }
+        const int32_t ebase = h.edge_base + pre_e;
+        const int32_t nbase = h.node_base + pre_n;
+        if (tile == n_tiles - 1 && threadIdx.x == 0) { // hop totals: update_counter + what k_resolve needs
+            const int32_t n_edges = pre_e + a.tile_edge[tile], n_nodes = pre_n + a.tile_node[tile];
+            a.hs->n_edges = n_edges;
+            a.hs->n_nodes = n_nodes;
+            apply_update_counter(a.nc, a.ec, a.op_id, a.hops, n_nodes, n_edges);
+        }
 #pragma unroll
         for (int s = 0; s < S; s++) {
             if (c[s] == -1) continue;
@@ -723,12 +721,10 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
     else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
-    k_mark<<<grid, kBlock, 0, s>>>(b.nc, count, b.pos_map, b.epoch, b.cand, b.aux, b.tile_node);
-    HIP_CHECK_LAST();
-    k_scan_tiles<<<1, kScanBlock, 0, s>>>(b.nc, b.ec, count, op_id, hops, b.tile_edge, b.tile_node, b.hop_state);
+    k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.pos_map, b.epoch, b.cand, b.aux, b.tile_node, b.hop_state);
     HIP_CHECK_LAST();
     WriteArgs w;
-    w.hs = b.hop_state; w.cand = b.cand; w.aux = b.aux; w.epoch = b.epoch; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
+    w.hs = b.hop_state; w.nc = b.nc; w.ec = b.ec; w.hops = hops; w.cand = b.cand; w.aux = b.aux; w.epoch = b.epoch; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
     w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
     w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id; w.last_hop = (op_id / 2 == hops) ? 1 : 0;
     k_write<<<grid, kBlock, 0, s>>>(w);

@@ -197,14 +197,22 @@ def main():
     elapsed_max, (job_edges, job_nodes, job_bytes) = D.aggregate(
         elapsed, [tot_edges, tot_nodes, float(samp_bytes.sum() + gather_bytes.sum())], world, device=dev)
 
-    # dominant kernel (k_gather: it moves ~90 % of the batch's algorithmic bytes), HIP events on our stream
+    # dominant kernel (k_gather: it moves ~94 % of the batch's algorithmic bytes), HIP events on its stream
     roofline = None
     if not per_level:
         g_ms = np.array([L.d_event_elapsed_ms(a, b) for a, b in ev], dtype=np.float64)
         ach = float(gather_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel="k_gather<float4,4>", achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                        frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
-                        avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and os.path.exists(pmc):
+            # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+            # command (counters cannot be read from inside the process); gfx950 FETCH_SIZE x2 correction applied
+            with open(pmc) as f:
+                traffic = json.load(f)["k_gather"]["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01_pmc_hbm_traffic.json"
+        roofline = dict(bound="hbm", kernel="k_gather<float4, 2 in flight, non-temporal>", achieved=round(ach, 1),
+                        peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
+                        traffic_source=traffic_src, avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),
                         algorithmic_bytes_per_launch=int(gather_bytes.mean()),
                         pipeline_frac=round(job_bytes / elapsed_max / 1e9 / (HBM_PEAK_GBPS * world), 4))
 

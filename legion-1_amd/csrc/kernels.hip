@@ -107,7 +107,16 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
         } else {
             int32_t src_id = all_ids[g % total_cap];
             batch_ids[idx] = src_id;
-            pos_map[src_id] = ((unsigned long long)epoch << 32) | (uint32_t)idx;
+            // position_map[src_id] = idx (Kernels.cu:92).  The reference assumes distinct seeds (:67); with
+            // duplicates (link-prediction triples) its serial order lets the LAST occurrence win, so do the
+            // same deterministically: the largest idx of the running epoch survives.
+            const unsigned long long mine = ((unsigned long long)epoch << 32) | (uint32_t)idx;
+            unsigned long long cur = pos_map[src_id];
+            while ((cur >> 32) != epoch || cur < mine) {
+                const unsigned long long seen = atomicCAS(pos_map + src_id, cur, mine);
+                if (seen == cur) break;
+                cur = seen;
+            }
             labels[idx] = all_labels[g % total_cap];
         }
     }
@@ -415,12 +424,13 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             const int32_t dst = (int32_t)((uint32_t)c[s] & 0x7FFFFFFFu);
             const int32_t e = ebase + pe + re[s];
             a.agg_src_ids[e] = dst;
-            // dst-side offset = position of the slot's source node: hop 1 sources are the seeds
-            // (position == index), later hops' sources are the previous hop's edge endpoints whose
-            // positions are that hop's src-side offsets.  Same value as position_map[src]
-            // (construct_graph, Kernels.cu:457-461) without the random read.
+            // dst-side offset = position of the slot's source node; for hops > 1 the sources are the
+            // previous hop's edge endpoints, whose positions are that hop's src-side offsets: same value
+            // as position_map[src] (construct_graph, Kernels.cu:457-461) without the random read.
             const int32_t i = (int32_t)fdiv((uint32_t)idx, a.fdiv);
-            a.agg_dst_off[e] = (a.op_id == 2) ? i : a.agg_src_off[h.in_off + i];
+            // hop 1: the seed's position.  That is i unless the seed list holds duplicates (link-prediction
+            // triples), where the reference's position_map keeps the last occurrence -- read it (<= B*f probes).
+            a.agg_dst_off[e] = (a.op_id == 2) ? (int32_t)(uint32_t)a.pos_map[a.sampled_ids[i]] : a.agg_src_off[h.in_off + i];
             int32_t so = a.aux[idx]; // known position (>= 0) or -2 - <winning slot> (k_resolve reads that slot's aux)
             if (c[s] < 0) {
                 const int32_t p = nbase + pn + rn[s];

@@ -263,3 +263,39 @@ def meta_config_line(ds: Dataset, path: str, batch_size: int, cache_bytes: int, 
     return "{} {} {} {} {} {} {} {} {} {} {}".format(path if path.endswith("/") else path + "/", batch_size, s.V,
                                                     ds.E, s.F, s.n_train, s.n_valid, s.n_test, cache_bytes,
                                                     epochs, partition_flag)
+
+
+def lp_trainingset(ds: Dataset, n_triples: int, batch_size: int, seed: int = 1) -> np.ndarray:
+    """Seed list for the link-prediction trainer (reference: pytorch_extension/lp_sage.py:87-90).
+
+    lp_sage.py splits the model output of a batch into three equal thirds ``[src | pos | neg]``; the
+    reference server has no edge / negative sampler, so the seed file itself must be laid out that way.
+    Every batch of ``batch_size`` (a multiple of 3) seeds is ``k = batch_size/3`` source nodes, then for
+    each of them one positive (a neighbour drawn with the sampler's own minstd stream: slot index =
+    global triple number) and one negative (uniform node id from the next minstd value).  Duplicates
+    inside a batch are legal: the pipeline keeps the reference's "last occurrence wins" position rule.
+    """
+    assert batch_size % 3 == 0
+    k = batch_size // 3
+    m31 = 2147483647
+    out = np.empty((n_triples + k - 1) // k * batch_size, dtype=np.int32)
+    srcs = ds.train[np.arange(n_triples) % len(ds.train)]
+    x = pow(48271, seed, m31)
+    for t in range(n_triples):
+        s = int(srcs[t])
+        lo, hi = int(ds.indptr[s]), int(ds.indptr[s + 1])
+        x = (x * 48271) % m31
+        pos = int(ds.indices[lo + (x - 1) % (hi - lo)]) if hi > lo else s
+        x = (x * 48271) % m31
+        neg = (x - 1) % ds.spec.V
+        b, i = divmod(t, k)
+        out[b * batch_size + i] = s
+        out[b * batch_size + k + i] = pos if pos >= 0 else s
+        out[b * batch_size + 2 * k + i] = neg
+    tail = n_triples % k
+    if tail:                     # pad the last batch by repeating its first triple
+        b = n_triples // k
+        for i in range(tail, k):
+            for part in range(3):
+                out[b * batch_size + part * k + i] = out[b * batch_size + part * k]
+    return out

@@ -17,8 +17,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "legion_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, n) for n in ("legion_oracle.c", "dgl_cpu_sampler.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liblegion_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -272,3 +272,44 @@ def schedule(steps, epoch, global_batch_id):
 def max_step(steps, epoch):
     s = np.asarray(steps, dtype=np.int32)
     return int(lib().lo_get_max_step(_p(s), C.c_int32(epoch)))
+
+
+class DglSemanticsSampler:
+    """DGL-semantics CPU baseline (oracle/dgl_cpu_sampler.c): uniform sampling without replacement,
+    to_block compaction per layer, feature index_select; OpenMP.  Not a parity reference."""
+
+    def __init__(self, indptr, indices, features, V, F, batch_size, fanout):
+        L = lib()
+        L.dgl_threads.restype = C.c_int32
+        L.dgl_sample_batch.restype = C.c_int64
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        self.indices = np.ascontiguousarray(indices, dtype=np.int32)
+        self.features = None if features is None else np.ascontiguousarray(features, dtype=np.float32)
+        self.V, self.F = int(V), int(F)
+        self.fanout = np.asarray(fanout, dtype=np.int32)
+        nodes, scratch, edges = batch_size, 0, 0
+        for f in fanout:
+            scratch = max(scratch, nodes * f)
+            edges += nodes * f
+            nodes = nodes * (1 + f)
+        self.local_map = np.full(self.V, -1, dtype=np.int32)
+        self.nodes = np.empty(nodes, dtype=np.int32)
+        self.src = np.empty(edges, dtype=np.int32)
+        self.dst = np.empty(edges, dtype=np.int32)
+        self.scratch = np.empty(scratch, dtype=np.int32)
+        self.edge_off = np.zeros(len(fanout) + 1, dtype=np.int64)
+        self.feat = None
+        self.threads = int(L.dgl_threads())
+
+    def run_batch(self, seeds, rng_seed=1, gather=True):
+        L = lib()
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        if gather and self.features is not None and self.feat is None:
+            self.feat = np.empty((len(self.nodes), self.F), dtype=np.float32)
+        ne = C.c_int64(0)
+        fo = self.feat if (gather and self.features is not None) else None
+        n = L.dgl_sample_batch(_p(self.indptr), _p(self.indices), _p(self.features) if fo is not None else None,
+                               C.c_int32(self.F), _p(seeds), C.c_int32(len(seeds)), _p(self.fanout),
+                               C.c_int32(len(self.fanout)), C.c_uint64(rng_seed), _p(self.local_map), _p(self.nodes),
+                               _p(self.src), _p(self.dst), _p(self.edge_off), _p(fo), _p(self.scratch), C.byref(ne))
+        return int(n), int(ne.value)

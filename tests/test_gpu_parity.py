@@ -397,3 +397,21 @@ def test_full_size_properties(K, synth, workload, fan):
     eng.run_batch(0, 0)
     assert_batch_equal(again, eng.result(0))
     eng.close()
+
+
+def test_link_prediction_seed_batches(K, oracle, synth, small_ds):
+    """[src | pos | neg] seed thirds with duplicates inside a batch (lp_sage.py:87-90)."""
+    ds = small_ds
+    B, fan = 96, [5, 3]
+    seeds = synth.lp_trainingset(ds, 300, B, seed=3)
+    seeds[5] = seeds[40]
+    seeds[B + 7] = seeds[B + 8]
+    seeds[2 * B + 1] = seeds[2 * B + 90]
+    lab = ds.labels[seeds]
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan, seeds=dict(train=[(seeds, lab)]))
+    for counter in range(len(seeds) // B):
+        ref = orc.run_batch(seeds, lab, counter)
+        eng.run_batch(0, counter)
+        assert_batch_equal(ref, eng.result(0))
+    eng.close()

@@ -136,3 +136,27 @@ def test_short_last_batch_quirk(oracle):
     res = r.run_batch(seeds, labels[seeds], 1)       # 6 seeds, batch 4, counter 1 -> size 2, offset 2*1
     assert res["nc"][4] == 2
     assert res["ids"][:2].tolist() == seeds[2:4].tolist()
+
+
+def test_link_prediction_seed_layout(oracle, synth, small_ds):
+    """lp_sage.py:87-90 -- seed batches laid out as [src | pos | neg] thirds; duplicates inside a batch
+    follow the reference's last-occurrence-wins position rule (position_map[src_id] = idx, Kernels.cu:92)."""
+    ds = small_ds
+    B = 96
+    seeds = synth.lp_trainingset(ds, 200, B, seed=3)
+    assert len(seeds) % B == 0
+    k = B // 3
+    first = seeds[:B]
+    for i in range(k):
+        row = ds.indices[ds.indptr[first[i]]:ds.indptr[first[i] + 1]]
+        assert first[k + i] in row and 0 <= first[2 * k + i] < ds.spec.V
+    # force duplicates inside a batch
+    seeds[5] = seeds[40]
+    seeds[B + 7] = seeds[B + 8]
+    lab = ds.labels[seeds]
+    r = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, [5, 3])
+    for counter in (0, 1):
+        res = r.run_batch(seeds, lab, counter)
+        ref = pyref.run_batch(ds.indptr, ds.indices, ds.features, seeds, lab, B, counter, [5, 3])
+        assert_batch_equal(ref, res)
+        assert res["ids"][:B].tolist() == seeds[counter * B:(counter + 1) * B].tolist()   # thirds stay in place

@@ -39,6 +39,11 @@ def parse():
     ap.add_argument("--gather", default="all", choices=["all", "level"], help="one gather per batch or one per level")
     ap.add_argument("--pipeline", default="serial", choices=["overlap", "serial"],
                     help="overlap: gather of batch i on a second stream while batch i+1 is sampled (depth-2 pipes)")
+    ap.add_argument("--cache", default="replicated", choices=["replicated", "unified"],
+                    help="replicated: every GPU holds all features (Kg=1).  unified: the clique-wide hotness-partitioned "
+                         "feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
+    ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
+    ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
     return ap.parse_args()
@@ -81,8 +86,12 @@ def main():
     import legion1_amd.capi as K
     import legion1_amd.synth as S
     L = K.lib()
-    L.legion_set_device_map(0, local_rank)  # this process drives one logical GPU (dev 0 of a 1-partition world)
-    L.SetGPUDevice(0)
+    unified = args.cache == "unified"
+    G = world if unified else 1          # logical GPUs of the clique this process knows about
+    me = rank if unified else 0          # the one this process drives
+    for g in range(G):
+        L.legion_set_device_map(g, local_rank)
+    L.SetGPUDevice(me)
 
     fan = [int(x) for x in args.fanout.split(",")]
     H = len(fan)
@@ -106,13 +115,19 @@ def main():
     n_mine = int(mine.numel())
     gen_s = time.time() - t0
 
-    seeds = dict(train=[((mine.data_ptr(), n_mine), (my_labels.data_ptr(), n_mine))])
+    empty = (np.zeros(0, np.int32), np.zeros(0, np.int32))
+    seeds = dict(train=[((mine.data_ptr(), n_mine), (my_labels.data_ptr(), n_mine)) if g == me else empty for g in range(G)])
     overlap = args.pipeline == "overlap" and args.gather == "all"
     depth = 2 if overlap else 1
-    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=1,
-                   csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E, pipeline_depth=depth)
+    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=G,
+                   csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E, pipeline_depth=depth,
+                   local_devs=[me], train_step=max(1, args.presc_steps))
     eng.alloc_features()
-    L.GPUCache_SetPreSc(eng.cache, 0)  # steady state: no pre-sampling epoch in the all-resident configuration
+    cache_info = None
+    if unified:
+        cache_info = build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev)
+    else:
+        L.GPUCache_SetPreSc(eng.cache, 0)  # steady state: no pre-sampling epoch in the all-resident configuration
     stream = L.d_stream_create()       # sampler stream
     gstream = L.d_stream_create() if overlap else stream   # gather stream (reference: streams_[1], Server.cu:178-181)
     steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
@@ -121,7 +136,7 @@ def main():
     per_level = args.gather == "level"
     log = K.DevBuf((K_steps + W) * 128)  # nc/ec of every step, copied on-stream
     ev = [(L.d_event_create(), L.d_event_create()) for _ in range(K_steps)]
-    pool = eng.pools[0]
+    pool = eng.pools[me]
     ev_sampled = [L.d_event_create() for _ in range(depth)]   # sampling of the batch in pipe q is complete
     ev_gathered = [L.d_event_create() for _ in range(depth)]  # gather of the batch in pipe q is complete
     used = [False] * depth
@@ -132,18 +147,18 @@ def main():
         only after its gather finished."""
         it = i % steps_avail
         q = i % depth
-        o = eng.out[0][q]
+        o = eng.out[me][q]
         L.GPUMemoryPool_SetCurrentPipe(pool, q)
         L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
         if overlap and used[q]:
             L.d_stream_wait_event(stream, ev_gathered[q])
-        L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, it, 0, 0, K.TRAINMODE)
+        L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, it, me, me, K.TRAINMODE)
         if per_level:
-            L.get_feature_kernel(stream, eng.cache, eng.noder, pool, 0, 1, 1)
+            L.get_feature_kernel(stream, eng.cache, eng.noder, pool, me, 1, 1)
         for h in range(H):
             L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
             if per_level:
-                L.get_feature_kernel(stream, eng.cache, eng.noder, pool, 0, 2 * h + 3, 1)
+                L.get_feature_kernel(stream, eng.cache, eng.noder, pool, me, 2 * h + 3, 1)
         L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
         L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
         if not per_level:
@@ -152,14 +167,14 @@ def main():
                 L.d_stream_wait_event(gstream, ev_sampled[q])
             if timed_idx is not None:
                 L.d_event_record(ev[timed_idx][0], gstream)
-            L.get_feature_kernel_all(gstream, eng.cache, eng.noder, pool, 0, 1)
+            L.get_feature_kernel_all(gstream, eng.cache, eng.noder, pool, me, 1)
             if timed_idx is not None:
                 L.d_event_record(ev[timed_idx][1], gstream)
             if overlap:
                 L.d_event_record(ev_gathered[q], gstream)
                 used[q] = True
-        L.make_update_plan(stream, eng.graph, eng.cache, pool, 0, K.TRAINMODE)
-        L.update_cache(stream, eng.cache, eng.noder, pool, 0, K.TRAINMODE)
+        L.make_update_plan(stream, eng.graph, eng.cache, pool, me, K.TRAINMODE)
+        L.update_cache(stream, eng.cache, eng.noder, pool, me, K.TRAINMODE)
 
     def drain():
         L.d_stream_sync(stream)
@@ -204,7 +219,7 @@ def main():
         ach = float(gather_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and os.path.exists(pmc):
+        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and not unified and os.path.exists(pmc):
             # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
             # command (counters cannot be read from inside the process); gfx950 FETCH_SIZE x2 correction applied
             with open(pmc) as f:
@@ -215,6 +230,12 @@ def main():
                         traffic_source=traffic_src, avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),
                         algorithmic_bytes_per_launch=int(gather_bytes.mean()),
                         pipeline_frac=round(job_bytes / elapsed_max / 1e9 / (HBM_PEAK_GBPS * world), 4))
+
+    xgmi = None
+    if unified and roofline is not None:
+        xgmi = unified_cache_traffic(K, L, eng, me, world, V, F, cache_info, float(np.mean([L.d_event_elapsed_ms(a, b) for a, b in ev])), dev)
+    if world > 1:
+        torch.distributed.barrier()   # nobody unmaps a cache shard while a peer may still read it
 
     cpu_baseline = None
     if rank == 0 and args.cpu_baseline_seconds > 0:
@@ -234,7 +255,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int32 ids / f32 rows (verbatim copy)",
             "data": "synthetic",
-            "config": {"workload": f"{spec.name}-shape synthetic graph, {H}-hop fan-out {fan}, batch {B}, CSR + features resident in HBM (Kg=1 replicas)",
+            "config": {"workload": f"{spec.name}-shape synthetic graph, {H}-hop fan-out {fan}, batch {B}, CSR + features resident in HBM" + (" (Kg=1 replicas)" if not unified else f", unified feature cache over the {world}-GPU clique"),
                        "V": V, "E": E, "F": F, "batch": B, "fanout": fan, "gather": args.gather, "pipeline": args.pipeline if args.gather == "all" else "serial", "seeds_per_rank": n_mine,
                        "parallelism": f"dp{world} (seed shards tid % {world}, no data-path collective)"},
             "feature_GBps": round(job_nodes * 4 * F / elapsed_max / 1e9, 2),
@@ -242,6 +263,7 @@ def main():
             "edges_per_batch": round(job_edges / (K_steps * world), 1),
             "unique_nodes_per_batch": round(job_nodes / (K_steps * world), 1),
             "graph_gen_s": round(gen_s, 2),
+            "cache": {"mode": args.cache, **(cache_info or {}), **(xgmi or {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
@@ -249,6 +271,53 @@ def main():
     eng.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
+    """Server::PreSc (Server.cu:83-114) for one process per GPU: pre-sampling epoch on the own seed shard, the
+    clique-wide hotness sum as an RCCL all-reduce (the reference reads its peers' arrays, GPUCache.cu:624-627),
+    ranking + fill-up of the OWN shard (rank-t row on GPU t % N), then a HIP-IPC exchange of the shards."""
+    H = len(fan)
+    pool = eng.pools[me]
+    for it in range(args.presc_steps):
+        L.GPUMemoryPool_SetCurrentPipe(pool, 0)
+        L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        L.batch_generator_kernel(None, eng.noder, eng.cache, pool, B, it, me, me, K.TRAINMODE)
+        for h in range(H):
+            L.GPU_Random_Sampling(None, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 1)
+        L.make_update_plan(None, eng.graph, eng.cache, pool, me, K.TRAINMODE)
+    L.d_stream_sync(None)
+    K.check()
+    D.allreduce_device_u64(K, L.GPUCache_GetNodeAccessedMap(eng.cache, me), V, world, device=dev)
+    D.allreduce_device_u64(K, L.GPUCache_GetEdgeAccessedMap(eng.cache, me), V, world, device=dev)
+    rows = int(V * args.cache_frac) // world + 1
+    mode = {1: 0, 2: 1, 4: 2, 8: 3}[world]
+    eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=0, train_step=args.presc_steps)
+    everyone = D.allgather_object(eng.export_shards(me), world)
+    for g in range(world):
+        if g != me:
+            eng.import_shards(g, everyone[g])
+    return {"Kg": world, "rows_per_gpu": rows, "cached_fraction_of_V": round(rows * world / V, 4), "presc_steps": args.presc_steps,
+            "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)"}
+
+
+def unified_cache_traffic(K, L, eng, me, world, V, F, cache_info, gather_ms, dev):
+    """Where the rows of the last batch came from: own shard / peer shards (xGMI) / backing table."""
+    o = eng.out[me][0]
+    nc = o["nc"].to_numpy(np.int32, 16)
+    n = int(nc[0])
+    ids = torch.from_numpy(o["ids"].to_numpy(np.int32, n).astype(np.int64)).to(dev)
+    fmap = torch.empty(V, dtype=torch.int32, device=dev)
+    L.d_copy_async(fmap.data_ptr(), L.GPUCache_GetFeatureMap(eng.cache, me), V * 4, None)
+    L.d_stream_sync(None)
+    slot = fmap[ids]
+    owner = torch.div(slot, cache_info["rows_per_gpu"], rounding_mode="floor")
+    local = int(((slot >= 0) & (owner == me)).sum().item())
+    peer = int(((slot >= 0) & (owner != me)).sum().item())
+    miss = int((slot < 0).sum().item())
+    return {"rows_last_batch": {"own_shard": local, "peer_shards": peer, "backing_table": miss},
+            "xgmi_read_GBps_per_gpu": round(peer * 4 * F / (gather_ms * 1e-3) / 1e9, 1) if world > 1 else 0.0,
+            "xgmi_peak_GBps_per_gpu": 7 * 153}
 
 
 def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail):

@@ -58,6 +58,12 @@ void legion_clear_error(void);
  * exercised on fewer physical devices. */
 void legion_set_device_map(int32_t logical_dev, int32_t physical_dev);
 int32_t legion_physical_device(int32_t logical_dev);
+/* One process per GPU: mark the logical GPUs of a clique that another process drives.  Their
+ * controllers hold nothing here; their cache shards / CSR fragments are imported over HIP IPC
+ * (GPUCache_ImportFeatureShard, GPUGraphStorage_ImportFragment) and then read in-kernel over xGMI,
+ * exactly like the reference's NVLink peer loads (Kernels.cu:395-409,698). */
+void legion_set_remote_device(int32_t logical_dev, int is_remote);
+int legion_is_remote_device(int32_t logical_dev);
 
 /* ---- raw device helpers: src/Kernels.cuh:24-45 (same names) ------------------------------ */
 void* d_alloc_space(int64_t num_bytes);
@@ -123,6 +129,10 @@ int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g);
 /* fragment of logical GPU part_id as seen from dev_id (NULL when not cached) */
 int64_t* GPUGraphStorage_GetFragmentIndex(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id);
 int32_t* GPUGraphStorage_GetFragmentMatrix(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id);
+/* HIP-IPC exchange of a clique member's fragment (64-byte handles); returns 0 on success */
+int GPUGraphStorage_ExportFragment(GPUGraphStorage* g, int32_t dev_id, void* handle_indptr64, void* handle_indices64, int32_t* rows_out);
+int GPUGraphStorage_ImportFragment(GPUGraphStorage* g, int32_t owner_dev, int32_t viewer_dev, const void* handle_indptr64,
+                                   const void* handle_indices64, int32_t rows);
 void GPUGraphStorage_Delete(GPUGraphStorage* g);
 
 /* ---- node storage: GPU_Node_Storage.cuh:24-61, GPU_Memory_Node_Storage.cu:11-161 ---------- */
@@ -212,9 +222,14 @@ void GPUCache_SetPreSc(GPUCache* c, int is_presc);
 void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph);
 int32_t GPUCache_MaxIdNum(const GPUCache* c, int32_t dev_id);
 float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);
+/* HIP-IPC exchange of a clique member's feature shard (64-byte handle); returns 0 on success */
+int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64);
+int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle64);
 uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id);
 uint64_t* GPUCache_GetEdgeAccessedMap(const GPUCache* c, int32_t dev_id);
 /* ranked candidate lists of clique Ki (device pointers on the clique's first GPU): QF / QT */
+/* direct-mapped id -> global cache slot table of dev_id (the reference's node_map_, GPUCache.cu:481): int32[V] */
+int32_t* GPUCache_GetFeatureMap(const GPUCache* c, int32_t dev_id);
 int32_t* GPUCache_GetQF(const GPUCache* c, int32_t Ki);
 int32_t* GPUCache_GetQT(const GPUCache* c, int32_t Ki);
 int32_t GPUCache_Kg(const GPUCache* c);

@@ -55,6 +55,8 @@ _SIGS = {
     "legion_set_error_mode": (None, [C.c_int]),
     "legion_set_device_map": (None, [i32, i32]),
     "legion_physical_device": (i32, [i32]),
+    "legion_set_remote_device": (None, [i32, C.c_int]),
+    "legion_is_remote_device": (C.c_int, [i32]),
     "d_alloc_space": (vp, [i64]),
     "d_free_space": (None, [vp]),
     "host_alloc_space64": (vp, [i64]),
@@ -79,6 +81,8 @@ _SIGS = {
     "GPUGraphStorage_Finalize": (None, [vp]),
     "GPUGraphStorage_Delete": (None, [vp]),
     "GPUGraphStorage_GetFragmentIndex": (vp, [vp, i32, i32]),
+    "GPUGraphStorage_ExportFragment": (C.c_int, [vp, i32, vp, vp, vp]),
+    "GPUGraphStorage_ImportFragment": (C.c_int, [vp, i32, i32, vp, vp, i32]),
     "GPUGraphStorage_GetFragmentMatrix": (vp, [vp, i32, i32]),
     "NewGPUMemoryNodeStorage": (vp, []),
     "GPUNodeStorage_Build": (None, [vp, vp]),
@@ -118,8 +122,11 @@ _SIGS = {
     "GPUCache_FillUp": (None, [vp, C.c_int, vp, vp]),
     "GPUCache_MaxIdNum": (i32, [vp, i32]),
     "GPUCache_Float_Feature_Cache": (vp, [vp, i32]),
+    "GPUCache_ExportFeatureShard": (C.c_int, [vp, i32, vp]),
+    "GPUCache_ImportFeatureShard": (C.c_int, [vp, i32, vp]),
     "GPUCache_GetNodeAccessedMap": (vp, [vp, i32]),
     "GPUCache_GetEdgeAccessedMap": (vp, [vp, i32]),
+    "GPUCache_GetFeatureMap": (vp, [vp, i32]),
     "GPUCache_GetQF": (vp, [vp, i32]),
     "GPUCache_GetQT": (vp, [vp, i32]),
     "GPUCache_Kg": (i32, [vp]),
@@ -254,8 +261,12 @@ class Engine:
 
     def __init__(self, indptr, indices, features, V, F, seeds, batch_size, fanout, G=1,
                  csr_location=LOC_DEVICE, features_location=LOC_DEVICE, cache_memory=0, train_step=1, epoch=1,
-                 pipeline_depth=1, E=None):
+                 pipeline_depth=1, E=None, local_devs=None):
         L = lib()
+        # one process per GPU: the other members of the clique are remote (legion_set_remote_device)
+        self.local_devs = list(range(int(G))) if local_devs is None else list(local_devs)
+        for g in range(int(G)):
+            L.legion_set_remote_device(g, 0 if g in self.local_devs else 1)
         self.L, self.G, self.V, self.F = L, int(G), int(V), int(F)
         self.fanout = np.asarray(fanout, dtype=np.int32)
         self.hops = len(self.fanout)
@@ -323,8 +334,8 @@ class Engine:
         L.GPUCache_Initialize(self.cache, int(cache_memory), 0, self.F, int(train_step), self.G)
         check()
         self.depth = int(pipeline_depth)
-        self.pools, self.out = [], []
-        for g in range(self.G):
+        self.pools, self.out = [None] * self.G, [None] * self.G
+        for g in self.local_devs:
             L.SetGPUDevice(g)
             L.GPUCache_InitializeCacheController(self.cache, g, self.V)
             pool = L.NewGPUMemoryPool(self.depth)
@@ -343,15 +354,15 @@ class Engine:
                 L.GPUMemoryPool_SetNodeCounter(pool, o["nc"].ptr, q)
                 L.GPUMemoryPool_SetEdgeCounter(pool, o["ec"].ptr, q)
                 pipes.append(o)
-            self.pools.append(pool)
-            self.out.append(pipes)
+            self.pools[g] = pool
+            self.out[g] = pipes
         self.streams = [None] * self.G
         check()
 
     # ---- feature buffers ------------------------------------------------------------------------------
     def alloc_features(self, rows=None):
         rows = self.num_ids if rows is None else int(rows)
-        for g in range(self.G):
+        for g in self.local_devs:
             self.L.SetGPUDevice(g)
             for q in range(self.depth):
                 b = DevBuf(rows * self.F * 4)
@@ -415,9 +426,34 @@ class Engine:
         L.GPUCache_FillUp(self.cache, cache_agg_mode, self.noder, self.graph)
         check()
 
+    # ---- one process per GPU: exchange the clique's cache shards / CSR fragments over HIP IPC -----------------
+    def export_shards(self, dev):
+        """(feature_handle, indptr_handle, indices_handle, fragment_rows) of a LOCAL clique member."""
+        L = self.L
+        fh, ih, xh = (C.create_string_buffer(64) for _ in range(3))
+        rows = C.c_int32(0)
+        have_f = L.GPUCache_Float_Feature_Cache(self.cache, dev) and L.GPUCache_ExportFeatureShard(self.cache, dev, fh) == 0
+        have_t = L.GPUGraphStorage_GetFragmentIndex(self.graph, dev, dev) and \
+            L.GPUGraphStorage_ExportFragment(self.graph, dev, ih, xh, C.byref(rows)) == 0
+        check()
+        return (fh.raw if have_f else None, ih.raw if have_t else None, xh.raw if have_t else None, rows.value)
+
+    def import_shards(self, owner_dev, handles, viewer_devs=None):
+        """Open a REMOTE member's shards so that the local members read them in-kernel (xGMI peer loads)."""
+        L = self.L
+        fh, ih, xh, rows = handles
+        if fh is not None:
+            L.GPUCache_ImportFeatureShard(self.cache, owner_dev, fh)
+        if ih is not None:
+            for v in (self.local_devs if viewer_devs is None else viewer_devs):
+                L.GPUGraphStorage_ImportFragment(self.graph, owner_dev, v, ih, xh, rows)
+        check()
+
     def close(self):
         L = self.L
         for g, pool in enumerate(self.pools):
+            if pool is None:
+                continue
             L.SetGPUDevice(g)
             L.GPUMemoryPool_Delete(pool)
             for pipes in self.out[g]:

@@ -24,6 +24,14 @@ using namespace legion;
 #define MIN_INTERVAL 0.01 // GPUCache.cu:30
 #define CLS 64            // GPUCache.cu:31
 
+// first member of clique Ki that this process drives (-1: none)
+static int clique_home(int Ki, int Kg)
+{
+    for (int j = 0; j < Kg; j++)
+        if (!is_remote_device(Ki * Kg + j)) return Ki * Kg + j;
+    return -1;
+}
+
 static int kg_of_mode(int cache_agg_mode)
 {   // GPUCache.cu:593-607
     switch (cache_agg_mode) { case 0: return 1; case 1: return 2; case 2: return 4; case 3: return 8; default: return 0; }
@@ -46,6 +54,7 @@ void GPUCache_Initialize(GPUCache* c, int64_t cache_memory, int32_t int_attr_len
         c->ctl[i]->device_count = device_count;
     }
     c->float_feature_cache.assign(device_count, nullptr);
+    c->cache_imported.assign(device_count, false);
     c->cache_memory = cache_memory;
     c->int_attr_len = int_attr_len;
     c->float_attr_len = float_attr_len;
@@ -58,8 +67,9 @@ void GPUCache_InitializeCacheController(GPUCache* c, int32_t dev_id, int32_t tot
 {
     if (!c || dev_id < 0 || dev_id >= c->device_count) { LEGION_ARG_ERROR("InitializeCacheController: bad dev_id"); return; }
     CacheController* k = c->ctl[dev_id];
-    DeviceGuard guard(dev_id);
     k->device_idx = dev_id;
+    if (is_remote_device(dev_id)) return; // driven by another process: nothing lives here
+    DeviceGuard guard(dev_id);
     k->total_num_nodes = total_num_nodes;
     HIP_CHECK(hipMalloc(&k->node_access_time, (size_t)total_num_nodes * sizeof(unsigned long long)));
     HIP_CHECK(hipMemset(k->node_access_time, 0, (size_t)total_num_nodes * sizeof(unsigned long long)));
@@ -93,7 +103,11 @@ void GPUCache_Finalize(GPUCache* c, int32_t dev_id)
     if (k->d_global_count) (void)hipFree(k->d_global_count);
     k->node_access_time = k->edge_access_time = nullptr;
     k->d_max_ids = k->d_global_count = nullptr;
-    if (c->float_feature_cache[dev_id]) { (void)hipFree(c->float_feature_cache[dev_id]); c->float_feature_cache[dev_id] = nullptr; }
+    if (c->float_feature_cache[dev_id]) {
+        if (c->cache_imported[dev_id]) (void)hipIpcCloseMemHandle(c->float_feature_cache[dev_id]);
+        else (void)hipFree(c->float_feature_cache[dev_id]);
+        c->float_feature_cache[dev_id] = nullptr;
+    }
 }
 
 int32_t GPUCache_NodeCapacity(const GPUCache* c, int32_t dev_id)
@@ -168,7 +182,12 @@ void GPUCache_CandidateSelection(GPUCache* c, int cache_agg_mode, GPUNodeStorage
     for (auto p : c->AT) if (p) (void)hipFree(p);
     c->QF.clear(); c->QT.clear(); c->AF.clear(); c->AT.clear();
     for (int i = 0; i < Kc; i++) {
-        DeviceGuard guard(i * Kg);
+        const int home = clique_home(i, Kg);
+        if (home < 0) { // no member of this clique lives in this process
+            c->QF.push_back(nullptr); c->AF.push_back(nullptr); c->QT.push_back(nullptr); c->AT.push_back(nullptr);
+            continue;
+        }
+        DeviceGuard guard(home);
         for (int pass = 0; pass < 2; pass++) {
             int32_t* order = nullptr;
             unsigned long long* agg = nullptr;
@@ -177,6 +196,7 @@ void GPUCache_CandidateSelection(GPUCache* c, int cache_agg_mode, GPUNodeStorage
             HIP_CHECK(hipMemset(agg, 0, (size_t)V * sizeof(unsigned long long)));
             for (int j = 0; j < Kg; j++) { // peer reads of the clique members' hotness arrays (:624-627,644-647)
                 CacheController* k = c->ctl[i * Kg + j];
+                if (is_remote_device(i * Kg + j)) continue; // its hotness was summed in by the caller (RCCL all-reduce)
                 launch_aggregate_access(nullptr, agg, pass == 0 ? k->node_access_time : k->edge_access_time, V);
             }
             launch_iota(nullptr, order, V);
@@ -210,13 +230,14 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
     c->node_capacity.clear(); c->edge_capacity.clear(); c->alpha.clear();
     std::cout << "Start solve cost model" << std::endl;
     for (int i = 0; i < Kc; i++) {
-        if (c->capacity_forced) {
-            c->node_capacity.push_back(c->forced_node_capacity);
-            c->edge_capacity.push_back(c->forced_edge_capacity);
+        const int home = clique_home(i, Kg);
+        if (c->capacity_forced || home < 0) {
+            c->node_capacity.push_back(c->capacity_forced ? c->forced_node_capacity : 0);
+            c->edge_capacity.push_back(c->capacity_forced ? c->forced_edge_capacity : 0);
             c->alpha.push_back(-1.0);
             continue;
         }
-        DeviceGuard guard(i * Kg);
+        DeviceGuard guard(home);
         std::vector<uint64_t> h_node_prefix(V), h_edge_prefix(V), h_edge_mem_prefix(V);
         {
             uint64_t* d_tmp = nullptr;
@@ -251,7 +272,7 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
         else total_trans_of_topo = h_edge_prefix[V - 1]; // PCM-free estimate
         uint64_t total_trans_of_feat = 0;
         for (int j = 0; j < Kg; j++)
-            total_trans_of_feat += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, i * Kg + j) * train_step * F * (int64_t)sizeof(float)) / max_payload_size);
+            total_trans_of_feat += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, is_remote_device(i * Kg + j) ? home : i * Kg + j) * train_step * F * (int64_t)sizeof(float)) / max_payload_size);
 
         int64_t current_mem = 0;
         const int64_t steps = (total_mem - 1) / memory_step + 1;
@@ -299,6 +320,7 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
         const int32_t ncap = c->node_capacity[i], ecap = c->edge_capacity[i];
         for (int j = 0; j < Kg; j++) {
             const int dev = i * Kg + j;
+            if (is_remote_device(dev)) continue; // its shard is imported (GPUCache_ImportFeatureShard)
             DeviceGuard guard(dev);
             CacheController* k = c->ctl[dev];
             free_controller_maps(k);
@@ -320,13 +342,33 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
         }
     }
     std::cout << "Finish load feature cache\n";
-    for (int i = 0; i < c->Kc; i++) GPUGraphStorage_GraphCache(graph, c->QT[i], i, Kg, c->edge_capacity[i]);
+    for (int i = 0; i < c->Kc; i++)
+        if (c->QT[i]) GPUGraphStorage_GraphCache(graph, c->QT[i], i, Kg, c->edge_capacity[i]);
     std::cout << "Finish load topology cache\n";
 }
 
 float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id)
 {
     return (dev_id >= 0 && dev_id < c->device_count) ? c->float_feature_cache[dev_id] : nullptr;
+}
+int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64)
+{
+    if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || !c->float_feature_cache[dev_id] || c->cache_imported[dev_id]) { LEGION_ARG_ERROR("ExportFeatureShard: no local shard"); return -1; }
+    DeviceGuard guard(dev_id);
+    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, c->float_feature_cache[dev_id]));
+    return error_pending() ? -1 : 0;
+}
+int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle64)
+{
+    if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || !is_remote_device(dev_id)) { LEGION_ARG_ERROR("ImportFeatureShard: dev_id must be a remote member"); return -1; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof(h));
+    void* p = nullptr;
+    HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    if (!p) return -1;
+    c->float_feature_cache[dev_id] = (float*)p;
+    c->cache_imported[dev_id] = true;
+    return 0;
 }
 uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id)
 {
@@ -335,6 +377,10 @@ uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id)
 uint64_t* GPUCache_GetEdgeAccessedMap(const GPUCache* c, int32_t dev_id)
 {
     return (dev_id >= 0 && dev_id < c->device_count) ? (uint64_t*)c->ctl[dev_id]->edge_access_time : nullptr;
+}
+int32_t* GPUCache_GetFeatureMap(const GPUCache* c, int32_t dev_id)
+{
+    return (dev_id >= 0 && dev_id < c->device_count) ? c->ctl[dev_id]->feat_map : nullptr;
 }
 int32_t* GPUCache_GetQF(const GPUCache* c, int32_t Ki) { return (Ki >= 0 && Ki < (int)c->QF.size()) ? c->QF[Ki] : nullptr; }
 int32_t* GPUCache_GetQT(const GPUCache* c, int32_t Ki) { return (Ki >= 0 && Ki < (int)c->QT.size()) ? c->QT[Ki] : nullptr; }
@@ -350,7 +396,8 @@ void GPUCache_Delete(GPUCache* c)
         delete c->ctl[i];
     }
     for (size_t i = 0; i < c->QF.size(); i++) {
-        DeviceGuard guard((int)i * c->Kg);
+        if (!c->QF[i]) continue;
+        DeviceGuard guard(clique_home((int)i, c->Kg));
         if (c->QF[i]) (void)hipFree(c->QF[i]);
         if (c->QT[i]) (void)hipFree(c->QT[i]);
         if (c->AF[i]) (void)hipFree(c->AF[i]);

@@ -23,6 +23,7 @@ inline void check(hipError_t e, const char* file, int line)
 #define LEGION_ARG_ERROR(msg) ::legion::report_error(__FILE__, __LINE__, (msg), false)
 
 int physical_device(int logical);
+bool is_remote_device(int logical); // logical GPU driven by another process (one process per GPU)
 // RAII: switch to the physical device of a logical id, restore on scope exit
 struct DeviceGuard {
     int prev = -1;
@@ -166,6 +167,7 @@ struct GPUGraphStorage {
     std::vector<int64_t*> frag_indptr;
     std::vector<int32_t*> frag_indices;
     std::vector<int32_t> frag_rows;
+    std::vector<bool> frag_imported;         // fragment opened from another process' IPC handle
     // which fragments logical GPU d may read (its clique): table[d][p]
     std::vector<std::vector<int64_t*>> view_indptr;
     std::vector<std::vector<int32_t*>> view_indices;
@@ -208,6 +210,7 @@ struct GPUCache {
     int64_t cache_memory = 0;
     int32_t int_attr_len = 0, float_attr_len = 0, train_step = 0;
     std::vector<float*> float_feature_cache;         // per logical GPU
+    std::vector<bool> cache_imported;                // shard opened from another process' IPC handle
     bool is_presc = true;
     bool capacity_forced = false;
     int32_t forced_node_capacity = 0, forced_edge_capacity = 0;

@@ -12,6 +12,7 @@ static thread_local std::string t_last_error;
 static int g_dev_map[64];
 static bool g_dev_map_set[64];
 static std::mutex g_mu;
+static bool g_remote[64];
 
 void report_error(const char* file, int line, const char* msg, bool hip_failure)
 {
@@ -29,6 +30,8 @@ void report_error(const char* file, int line, const char* msg, bool hip_failure)
 }
 
 bool error_pending() { return !t_last_error.empty(); }
+
+bool is_remote_device(int logical) { return logical >= 0 && logical < 64 && g_remote[logical]; }
 
 int physical_device(int logical)
 {
@@ -69,6 +72,12 @@ void legion_set_device_map(int32_t logical_dev, int32_t physical_dev)
     g_dev_map_set[logical_dev] = true;
 }
 int32_t legion_physical_device(int32_t logical_dev) { return physical_device(logical_dev); }
+void legion_set_remote_device(int32_t logical_dev, int is_remote)
+{
+    if (logical_dev < 0 || logical_dev >= 64) { LEGION_ARG_ERROR("legion_set_remote_device: logical id out of range"); return; }
+    g_remote[logical_dev] = is_remote != 0;
+}
+int legion_is_remote_device(int32_t logical_dev) { return is_remote_device(logical_dev) ? 1 : 0; }
 
 // ---- Kernels.cu:14-64 ---------------------------------------------------------------------------
 void* d_alloc_space(int64_t num_bytes)

@@ -69,6 +69,7 @@ void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info)
     g->frag_indptr.assign(P, nullptr);
     g->frag_indices.assign(P, nullptr);
     g->frag_rows.assign(P, 0);
+    g->frag_imported.assign(P, false);
     g->view_indptr.assign(P, std::vector<int64_t*>(P, nullptr));
     g->view_indices.assign(P, std::vector<int32_t*>(P, nullptr));
 }
@@ -79,6 +80,7 @@ void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int
     if (!g || !QT || Kg < 1 || (Ki + 1) * Kg > g->partition_count) { LEGION_ARG_ERROR("GraphCache: bad clique"); return; }
     for (int i = 0; i < Kg; i++) {
         const int dev = Ki * Kg + i;
+        if (is_remote_device(dev)) continue; // built by its own process, imported here over IPC
         DeviceGuard guard(dev);
         if (g->frag_indptr[dev]) { (void)hipFree(g->frag_indptr[dev]); g->frag_indptr[dev] = nullptr; }
         if (g->frag_indices[dev]) { (void)hipFree(g->frag_indices[dev]); g->frag_indices[dev] = nullptr; }
@@ -113,8 +115,14 @@ void GPUGraphStorage_Finalize(GPUGraphStorage* g)
 {
     if (!g) return;
     for (size_t i = 0; i < g->frag_indptr.size(); i++) {
-        if (g->frag_indptr[i]) (void)hipFree(g->frag_indptr[i]);
-        if (g->frag_indices[i]) (void)hipFree(g->frag_indices[i]);
+        if (g->frag_imported[i]) {
+            if (g->frag_indptr[i]) (void)hipIpcCloseMemHandle(g->frag_indptr[i]);
+            if (g->frag_indices[i]) (void)hipIpcCloseMemHandle(g->frag_indices[i]);
+            g->frag_imported[i] = false;
+        } else {
+            if (g->frag_indptr[i]) (void)hipFree(g->frag_indptr[i]);
+            if (g->frag_indices[i]) (void)hipFree(g->frag_indices[i]);
+        }
         g->frag_indptr[i] = nullptr;
         g->frag_indices[i] = nullptr;
     }
@@ -136,6 +144,37 @@ int32_t* GPUGraphStorage_GetFragmentMatrix(const GPUGraphStorage* g, int32_t dev
 {
     if (dev_id < 0 || dev_id >= g->partition_count || part_id < 0 || part_id >= g->partition_count) return nullptr;
     return g->view_indices[dev_id][part_id];
+}
+int GPUGraphStorage_ExportFragment(GPUGraphStorage* g, int32_t dev_id, void* handle_indptr64, void* handle_indices64, int32_t* rows_out)
+{
+    if (!g || dev_id < 0 || dev_id >= g->partition_count || !g->frag_indptr[dev_id] || g->frag_imported[dev_id]) { LEGION_ARG_ERROR("ExportFragment: no local fragment"); return -1; }
+    DeviceGuard guard(dev_id);
+    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle_indptr64, g->frag_indptr[dev_id]));
+    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle_indices64, g->frag_indices[dev_id]));
+    if (rows_out) *rows_out = g->frag_rows[dev_id];
+    return error_pending() ? -1 : 0;
+}
+int GPUGraphStorage_ImportFragment(GPUGraphStorage* g, int32_t owner_dev, int32_t viewer_dev, const void* handle_indptr64,
+                                   const void* handle_indices64, int32_t rows)
+{
+    if (!g || owner_dev < 0 || owner_dev >= g->partition_count || viewer_dev < 0 || viewer_dev >= g->partition_count || !is_remote_device(owner_dev)) { LEGION_ARG_ERROR("ImportFragment: owner must be a remote member"); return -1; }
+    DeviceGuard guard(viewer_dev);
+    if (!g->frag_indptr[owner_dev]) {
+        hipIpcMemHandle_t h1, h2;
+        memcpy(&h1, handle_indptr64, sizeof(h1));
+        memcpy(&h2, handle_indices64, sizeof(h2));
+        void *p1 = nullptr, *p2 = nullptr;
+        HIP_CHECK(hipIpcOpenMemHandle(&p1, h1, hipIpcMemLazyEnablePeerAccess));
+        HIP_CHECK(hipIpcOpenMemHandle(&p2, h2, hipIpcMemLazyEnablePeerAccess));
+        if (!p1 || !p2) return -1;
+        g->frag_indptr[owner_dev] = (int64_t*)p1;
+        g->frag_indices[owner_dev] = (int32_t*)p2;
+        g->frag_rows[owner_dev] = rows;
+        g->frag_imported[owner_dev] = true;
+    }
+    g->view_indptr[viewer_dev][owner_dev] = g->frag_indptr[owner_dev];
+    g->view_indices[viewer_dev][owner_dev] = g->frag_indices[owner_dev];
+    return 0;
 }
 void GPUGraphStorage_Delete(GPUGraphStorage* g)
 {
@@ -173,6 +212,7 @@ void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
     n->training_set_ids.assign(P, nullptr); n->validation_set_ids.assign(P, nullptr); n->testing_set_ids.assign(P, nullptr);
     n->training_labels.assign(P, nullptr); n->validation_labels.assign(P, nullptr); n->testing_labels.assign(P, nullptr);
     for (int p = 0; p < P; p++) { // GPU_Memory_Node_Storage.cu:41-96
+        if (is_remote_device(p)) continue; // that partition's seed sets live in its own process
         DeviceGuard guard(p);
         if (info->training_set_num) {
             n->training_set_num[p] = info->training_set_num[p];

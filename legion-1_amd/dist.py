@@ -50,3 +50,37 @@ def aggregate(elapsed_s: float, totals, world: int, device=None):
 def throughput_line(job_units: float, elapsed_max_s: float, steps: int):
     """whole-job units/s and ms per step from the aggregated numbers."""
     return job_units / elapsed_max_s, elapsed_max_s / steps * 1e3
+
+
+def allreduce_device_u64(capi, ptr: int, n: int, world: int, device=None):
+    """In-place SUM over ranks of a u64[n] device array owned by the C library (the clique-wide hotness
+    sum of CandidateSelection, GPUCache.cu:624-627, as a collective instead of peer reads).
+    RCCL when the process group is nccl; with gloo (CPU tests) the array is staged through the host."""
+    if world <= 1:
+        return
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    L = capi.lib()
+    if dist.get_backend() == "nccl":
+        t = torch.empty(n, dtype=torch.int64, device=device)
+        L.d_copy_async(t.data_ptr(), ptr, n * 8, None)
+        L.d_stream_sync(None)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        L.d_copy_async(ptr, t.data_ptr(), n * 8, None)
+        L.d_stream_sync(None)
+    else:
+        h = capi.read_dev(ptr, np.int64, n)
+        t = torch.from_numpy(h)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        L.d_copy_h_2_d(ptr, h.ctypes.data, n * 8)
+
+
+def allgather_object(obj, world: int):
+    if world <= 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out

@@ -43,6 +43,7 @@ def parse():
                     help="replicated: every GPU holds all features (Kg=1).  unified: the clique-wide hotness-partitioned "
                          "feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
     ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
+    ap.add_argument("--allow-large-ipc", action="store_true", help="unified: do not cap cache shards at 1.5 GB (see build_unified_cache)")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
@@ -71,17 +72,28 @@ def build_graph_on_gpu(K, spec, dev):
 
 def main():
     args = parse()
+    if os.environ.get("LEGION_BENCH_WATCHDOG"):  # debugging aid: dump all Python stacks and exit if stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["LEGION_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    # Rehearsal on a one-GPU box: LEGION_BENCH_FORCE_DEVICE=0 puts every rank on that device and uses gloo
+    # (RCCL refuses two ranks on one GPU).  Never set on a real multi-GPU run.
+    forced = os.environ.get("LEGION_BENCH_FORCE_DEVICE")
+    if forced is not None:
+        local_rank = int(forced)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if forced is not None:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import legion1_amd.capi as K
     import legion1_amd.synth as S
@@ -291,12 +303,22 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
     D.allreduce_device_u64(K, L.GPUCache_GetNodeAccessedMap(eng.cache, me), V, world, device=dev)
     D.allreduce_device_u64(K, L.GPUCache_GetEdgeAccessedMap(eng.cache, me), V, world, device=dev)
     rows = int(V * args.cache_frac) // world + 1
+    # hipIpcOpenMemHandle of a >= 3.6 GB shard never returned on the (dmabuf-IPC) test box while 1.8 GB opens
+    # instantly (profiles/r01_unified_ipc_notes.md); until shards are exported in chunks, keep them below 1.5 GB.
+    if world > 1 and not args.allow_large_ipc:
+        rows = min(rows, int(1.5e9) // (4 * F))
     mode = {1: 0, 2: 1, 4: 2, 8: 3}[world]
     eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=0, train_step=args.presc_steps)
     everyone = D.allgather_object(eng.export_shards(me), world)
-    for g in range(world):
-        if g != me:
-            eng.import_shards(g, everyone[g])
+    for turn in range(world):          # one importer at a time (simultaneous cross-opens of large shards were seen to stall)
+        if turn == me:
+            t_imp = time.time()
+            for g in range(world):
+                if g != me:
+                    eng.import_shards(g, everyone[g])
+            if os.environ.get("LEGION_BENCH_WATCHDOG"):
+                print(f"[rank {me}] imported {world - 1} shard(s) of {rows * F * 4 / 1e9:.1f} GB in {time.time() - t_imp:.2f} s", flush=True)
+        D.barrier(world)
     return {"Kg": world, "rows_per_gpu": rows, "cached_fraction_of_V": round(rows * world / V, 4), "presc_steps": args.presc_steps,
             "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)"}
 

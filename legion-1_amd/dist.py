@@ -40,6 +40,8 @@ def aggregate(elapsed_s: float, totals, world: int, device=None):
         return float(elapsed_s), [float(t) for t in totals]
     import torch
     import torch.distributed as dist
+    if dist.get_backend() != "nccl":
+        device = None          # gloo: host tensors
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
     s = torch.tensor([float(x) for x in totals], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -250,7 +250,7 @@ def main():
         torch.distributed.barrier()   # nobody unmaps a cache shard while a peer may still read it
 
     cpu_baseline = None
-    if rank == 0 and args.cpu_baseline_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
         cpu_baseline = run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail)
 
     if rank == 0:

@@ -43,7 +43,6 @@ def parse():
                     help="replicated: every GPU holds all features (Kg=1).  unified: the clique-wide hotness-partitioned "
                          "feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
     ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
-    ap.add_argument("--allow-large-ipc", action="store_true", help="unified: do not cap cache shards at 1.5 GB (see build_unified_cache)")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
@@ -303,14 +302,10 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
     D.allreduce_device_u64(K, L.GPUCache_GetNodeAccessedMap(eng.cache, me), V, world, device=dev)
     D.allreduce_device_u64(K, L.GPUCache_GetEdgeAccessedMap(eng.cache, me), V, world, device=dev)
     rows = int(V * args.cache_frac) // world + 1
-    # hipIpcOpenMemHandle of a >= 3.6 GB shard never returned on the (dmabuf-IPC) test box while 1.8 GB opens
-    # instantly (profiles/r01_unified_ipc_notes.md); until shards are exported in chunks, keep them below 1.5 GB.
-    if world > 1 and not args.allow_large_ipc:
-        rows = min(rows, int(1.5e9) // (4 * F))
     mode = {1: 0, 2: 1, 4: 2, 8: 3}[world]
     eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=0, train_step=args.presc_steps)
     everyone = D.allgather_object(eng.export_shards(me), world)
-    for turn in range(world):          # one importer at a time (simultaneous cross-opens of large shards were seen to stall)
+    for turn in range(world):          # one importer at a time
         if turn == me:
             t_imp = time.time()
             for g in range(world):

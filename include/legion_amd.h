@@ -225,6 +225,13 @@ float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);
 /* HIP-IPC exchange of a clique member's feature shard (64-byte handle); returns 0 on success */
 int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64);
 int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle64);
+/* A shard is a list of chunk allocations (2^k rows each, <= $LEGION_SHARD_CHUNK_BYTES, default 1 GiB): shard row r is
+ * row r % ChunkRows of chunk r / ChunkRows.  Each chunk is exported / imported on its own. */
+int32_t GPUCache_ShardChunkCount(const GPUCache* c, int32_t dev_id);
+int32_t GPUCache_ShardChunkRows(const GPUCache* c, int32_t dev_id);
+float* GPUCache_GetShardChunk(const GPUCache* c, int32_t dev_id, int32_t chunk);
+int GPUCache_ExportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, void* handle64);
+int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, const void* handle64);
 uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id);
 uint64_t* GPUCache_GetEdgeAccessedMap(const GPUCache* c, int32_t dev_id);
 /* ranked candidate lists of clique Ki (device pointers on the clique's first GPU): QF / QT */

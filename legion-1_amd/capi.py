@@ -124,6 +124,11 @@ _SIGS = {
     "GPUCache_Float_Feature_Cache": (vp, [vp, i32]),
     "GPUCache_ExportFeatureShard": (C.c_int, [vp, i32, vp]),
     "GPUCache_ImportFeatureShard": (C.c_int, [vp, i32, vp]),
+    "GPUCache_ShardChunkCount": (i32, [vp, i32]),
+    "GPUCache_ShardChunkRows": (i32, [vp, i32]),
+    "GPUCache_GetShardChunk": (vp, [vp, i32, i32]),
+    "GPUCache_ExportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
+    "GPUCache_ImportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
     "GPUCache_GetNodeAccessedMap": (vp, [vp, i32]),
     "GPUCache_GetEdgeAccessedMap": (vp, [vp, i32]),
     "GPUCache_GetFeatureMap": (vp, [vp, i32]),
@@ -430,20 +435,28 @@ class Engine:
     def export_shards(self, dev):
         """(feature_handle, indptr_handle, indices_handle, fragment_rows) of a LOCAL clique member."""
         L = self.L
-        fh, ih, xh = (C.create_string_buffer(64) for _ in range(3))
+        ih, xh = (C.create_string_buffer(64) for _ in range(2))
         rows = C.c_int32(0)
-        have_f = L.GPUCache_Float_Feature_Cache(self.cache, dev) and L.GPUCache_ExportFeatureShard(self.cache, dev, fh) == 0
+        fh = []
+        if L.GPUCache_Float_Feature_Cache(self.cache, dev):
+            for q in range(L.GPUCache_ShardChunkCount(self.cache, dev)):
+                b = C.create_string_buffer(64)
+                if L.GPUCache_ExportFeatureShardChunk(self.cache, dev, q, b) != 0:
+                    break
+                fh.append(b.raw)
+        have_f = len(fh) > 0
         have_t = L.GPUGraphStorage_GetFragmentIndex(self.graph, dev, dev) and \
             L.GPUGraphStorage_ExportFragment(self.graph, dev, ih, xh, C.byref(rows)) == 0
         check()
-        return (fh.raw if have_f else None, ih.raw if have_t else None, xh.raw if have_t else None, rows.value)
+        return (fh if have_f else None, ih.raw if have_t else None, xh.raw if have_t else None, rows.value)
 
     def import_shards(self, owner_dev, handles, viewer_devs=None):
         """Open a REMOTE member's shards so that the local members read them in-kernel (xGMI peer loads)."""
         L = self.L
         fh, ih, xh, rows = handles
         if fh is not None:
-            L.GPUCache_ImportFeatureShard(self.cache, owner_dev, fh)
+            for q, h in enumerate(fh):
+                L.GPUCache_ImportFeatureShardChunk(self.cache, owner_dev, q, h)
         if ih is not None:
             for v in (self.local_devs if viewer_devs is None else viewer_devs):
                 L.GPUGraphStorage_ImportFragment(self.graph, owner_dev, v, ih, xh, rows)

@@ -55,6 +55,8 @@ void GPUCache_Initialize(GPUCache* c, int64_t cache_memory, int32_t int_attr_len
     }
     c->float_feature_cache.assign(device_count, nullptr);
     c->cache_imported.assign(device_count, false);
+    c->shard_chunks.assign(device_count, {});
+    c->d_shard_tab.assign(device_count, nullptr);
     c->cache_memory = cache_memory;
     c->int_attr_len = int_attr_len;
     c->float_attr_len = float_attr_len;
@@ -83,6 +85,34 @@ void GPUCache_InitializeCacheController(GPUCache* c, int32_t dev_id, int32_t tot
     HIP_CHECK(hipDeviceSynchronize());
 }
 
+static void free_shard(GPUCache* c, int dev)
+{
+    for (float* p : c->shard_chunks[dev]) {
+        if (!p) continue;
+        if (c->cache_imported[dev]) (void)hipIpcCloseMemHandle(p);
+        else (void)hipFree(p);
+    }
+    c->shard_chunks[dev].clear();
+    c->float_feature_cache[dev] = nullptr;
+    c->cache_imported[dev] = false;
+}
+
+// (re)write the device-side chunk-pointer tables of the local members of clique Ki
+static void publish_shard_tables(GPUCache* c, int Ki)
+{
+    const int Kg = c->Kg, nch = c->nchunks[Ki];
+    std::vector<float*> h((size_t)Kg * nch, nullptr);
+    for (int j = 0; j < Kg; j++)
+        for (size_t q = 0; q < c->shard_chunks[Ki * Kg + j].size() && (int)q < nch; q++) h[(size_t)j * nch + q] = c->shard_chunks[Ki * Kg + j][q];
+    for (int j = 0; j < Kg; j++) {
+        const int dev = Ki * Kg + j;
+        if (is_remote_device(dev)) continue;
+        DeviceGuard guard(dev);
+        if (!c->d_shard_tab[dev]) HIP_CHECK(hipMalloc(&c->d_shard_tab[dev], h.size() * sizeof(float*)));
+        HIP_CHECK(hipMemcpy(c->d_shard_tab[dev], h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice));
+    }
+}
+
 static void free_controller_maps(CacheController* k)
 {
     if (k->feat_map) (void)hipFree(k->feat_map);
@@ -103,11 +133,8 @@ void GPUCache_Finalize(GPUCache* c, int32_t dev_id)
     if (k->d_global_count) (void)hipFree(k->d_global_count);
     k->node_access_time = k->edge_access_time = nullptr;
     k->d_max_ids = k->d_global_count = nullptr;
-    if (c->float_feature_cache[dev_id]) {
-        if (c->cache_imported[dev_id]) (void)hipIpcCloseMemHandle(c->float_feature_cache[dev_id]);
-        else (void)hipFree(c->float_feature_cache[dev_id]);
-        c->float_feature_cache[dev_id] = nullptr;
-    }
+    free_shard(c, dev_id);
+    if (c->d_shard_tab[dev_id]) { (void)hipFree(c->d_shard_tab[dev_id]); c->d_shard_tab[dev_id] = nullptr; }
 }
 
 int32_t GPUCache_NodeCapacity(const GPUCache* c, int32_t dev_id)
@@ -316,8 +343,21 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
     const int32_t V = noder->total_num_nodes;
     const int32_t F = noder->float_attr_len;
     const int Kg = c->Kg;
+    c->chunk_shift.assign(c->Kc, 30);
+    c->nchunks.assign(c->Kc, 1);
+    // A shard is a list of chunk allocations (2^chunk_shift rows each, <= 1 GiB by default): a large single
+    // allocation could not be imported over HIP IPC on the test pool (profiles/r01_unified_ipc_notes.md).
+    const char* env_chunk = getenv("LEGION_SHARD_CHUNK_BYTES");
+    const int64_t chunk_bytes = env_chunk ? atoll(env_chunk) : (1ll << 30);
     for (int i = 0; i < c->Kc; i++) {
         const int32_t ncap = c->node_capacity[i], ecap = c->edge_capacity[i];
+        int shift = 0;
+        while (shift < 30 && (2ll << shift) * F * (int64_t)sizeof(float) <= chunk_bytes) shift++;
+        const int32_t rpc = 1 << shift;
+        c->chunk_shift[i] = shift;
+        c->nchunks[i] = ncap > 0 ? (ncap + rpc - 1) / rpc : 1;
+        for (int j = 0; j < Kg; j++)
+            if (c->d_shard_tab[i * Kg + j]) { (void)hipFree(c->d_shard_tab[i * Kg + j]); c->d_shard_tab[i * Kg + j] = nullptr; }
         for (int j = 0; j < Kg; j++) {
             const int dev = i * Kg + j;
             if (is_remote_device(dev)) continue; // its shard is imported (GPUCache_ImportFeatureShard)
@@ -331,15 +371,20 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
             HIP_CHECK(hipMalloc(&k->topo_row, (size_t)V * sizeof(int32_t)));
             launch_build_feat_map(nullptr, k->feat_map, c->QF[i], ncap, Kg, V);
             launch_build_topo_map(nullptr, k->topo_owner, k->topo_row, c->QT[i], ecap, Kg, i, V);
-            if (c->float_feature_cache[dev]) { (void)hipFree(c->float_feature_cache[dev]); c->float_feature_cache[dev] = nullptr; }
+            free_shard(c, dev);
             if (F > 0 && ncap > 0) {
-                float* cache = nullptr;
-                HIP_CHECK(hipMalloc(&cache, (size_t)ncap * F * sizeof(float)));
-                launch_feat_fill_up(nullptr, ncap, F, cache, noder->float_attrs, c->QF[i], Kg, j, V);
-                c->float_feature_cache[dev] = cache;
+                for (int q = 0; q < c->nchunks[i]; q++) {
+                    const int32_t row0 = q * rpc, rows = std::min(rpc, ncap - row0);
+                    float* chunk = nullptr;
+                    HIP_CHECK(hipMalloc(&chunk, (size_t)rows * F * sizeof(float)));
+                    launch_feat_fill_up(nullptr, row0, rows, F, chunk, noder->float_attrs, c->QF[i], Kg, j, V);
+                    c->shard_chunks[dev].push_back(chunk);
+                }
+                c->float_feature_cache[dev] = c->shard_chunks[dev][0];
             }
             HIP_CHECK(hipDeviceSynchronize());
         }
+        if (clique_home(i, Kg) >= 0) publish_shard_tables(c, i);
     }
     std::cout << "Finish load feature cache\n";
     for (int i = 0; i < c->Kc; i++)
@@ -351,24 +396,58 @@ float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id)
 {
     return (dev_id >= 0 && dev_id < c->device_count) ? c->float_feature_cache[dev_id] : nullptr;
 }
-int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64)
+int32_t GPUCache_ShardChunkCount(const GPUCache* c, int32_t dev_id)
 {
-    if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || !c->float_feature_cache[dev_id] || c->cache_imported[dev_id]) { LEGION_ARG_ERROR("ExportFeatureShard: no local shard"); return -1; }
+    if (!c || dev_id < 0 || dev_id >= c->device_count || c->nchunks.empty()) return 0;
+    return c->nchunks[dev_id / c->Kg];
+}
+int32_t GPUCache_ShardChunkRows(const GPUCache* c, int32_t dev_id)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count || c->chunk_shift.empty()) return 0;
+    return 1 << c->chunk_shift[dev_id / c->Kg];
+}
+float* GPUCache_GetShardChunk(const GPUCache* c, int32_t dev_id, int32_t chunk)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count || chunk < 0 || chunk >= (int)c->shard_chunks[dev_id].size()) return nullptr;
+    return c->shard_chunks[dev_id][chunk];
+}
+int GPUCache_ExportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, void* handle64)
+{
+    if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || c->cache_imported[dev_id] || chunk < 0 ||
+        chunk >= (int)c->shard_chunks[dev_id].size()) { LEGION_ARG_ERROR("ExportFeatureShardChunk: no such local chunk"); return -1; }
     DeviceGuard guard(dev_id);
-    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, c->float_feature_cache[dev_id]));
+    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, c->shard_chunks[dev_id][chunk]));
     return error_pending() ? -1 : 0;
 }
-int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle64)
+int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, const void* handle64)
 {
-    if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || !is_remote_device(dev_id)) { LEGION_ARG_ERROR("ImportFeatureShard: dev_id must be a remote member"); return -1; }
+    if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || !is_remote_device(dev_id) || c->nchunks.empty() || chunk < 0 ||
+        chunk >= c->nchunks[dev_id / c->Kg]) { LEGION_ARG_ERROR("ImportFeatureShardChunk: dev_id must be a remote member, chunk in range"); return -1; }
     hipIpcMemHandle_t h;
     memcpy(&h, handle64, sizeof(h));
     void* p = nullptr;
-    HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    {
+        const int home = clique_home(dev_id / c->Kg, c->Kg);
+        DeviceGuard guard(home >= 0 ? home : dev_id);
+        HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+    }
     if (!p) return -1;
-    c->float_feature_cache[dev_id] = (float*)p;
+    auto& v = c->shard_chunks[dev_id];
+    if ((int)v.size() <= chunk) v.resize(chunk + 1, nullptr);
+    v[chunk] = (float*)p;
     c->cache_imported[dev_id] = true;
+    if (chunk == 0) c->float_feature_cache[dev_id] = (float*)p;
+    publish_shard_tables(c, dev_id / c->Kg);
     return 0;
+}
+int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64)
+{   // single-chunk shards only; chunked shards use the *Chunk calls
+    if (GPUCache_ShardChunkCount(c, dev_id) != 1) { LEGION_ARG_ERROR("ExportFeatureShard: shard has several chunks, use ExportFeatureShardChunk"); return -1; }
+    return GPUCache_ExportFeatureShardChunk(c, dev_id, 0, handle64);
+}
+int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle64)
+{
+    return GPUCache_ImportFeatureShardChunk(c, dev_id, 0, handle64);
 }
 uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id)
 {

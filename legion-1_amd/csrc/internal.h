@@ -86,7 +86,11 @@ void launch_find_topo(hipStream_t s, const int32_t* input_ids, int8_t* part_inde
                       int32_t batch_size, const int8_t* topo_owner, const int32_t* topo_row);
 struct GatherArgs {
     const float* table;                       // V x F rows: the "cpu_float_attrs" of the reference
-    const float* cache[kMaxParts];            // clique caches (Global_Float_Feature_Cache)
+    // clique caches (Global_Float_Feature_Cache, the reference's float** cache_float_attrs): device table of
+    // Kg x nchunks chunk pointers; shard row r lives in chunk r >> chunk_shift (shards are allocated in
+    // chunks so that each piece can be exported over HIP IPC)
+    const float* const* shard_tab;
+    int32_t chunk_shift, nchunks;
     const int32_t* feat_map;                  // int32[V] global slot or -1; null = no cache
     int32_t cache_capacity;                   // rows per GPU
     int32_t F;
@@ -109,8 +113,8 @@ void launch_build_topo_map(hipStream_t s, int8_t* owner, int32_t* row, const int
                            int32_t Ki, int32_t V);
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
 void launch_fill_i8(hipStream_t s, int8_t* p, int8_t v, int64_t n);
-void launch_feat_fill_up(hipStream_t s, int32_t capacity, int32_t F, float* cache, const float* table, const int32_t* QF,
-                         int32_t Kg, int32_t Ki, int32_t V);
+void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, float* chunk, const float* table,
+                         const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V);
 void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
                            const int64_t* indptr, int64_t* count_out);
 void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
@@ -211,6 +215,9 @@ struct GPUCache {
     int32_t int_attr_len = 0, float_attr_len = 0, train_step = 0;
     std::vector<float*> float_feature_cache;         // per logical GPU
     std::vector<bool> cache_imported;                // shard opened from another process' IPC handle
+    std::vector<std::vector<float*>> shard_chunks;   // per logical GPU: the shard's chunk allocations
+    std::vector<float**> d_shard_tab;                // per LOCAL logical GPU: device table [Kg x nchunks]
+    std::vector<int32_t> chunk_shift, nchunks;       // per clique
     bool is_presc = true;
     bool capacity_forced = false;
     int32_t forced_node_capacity = 0, forced_edge_capacity = 0;

@@ -529,7 +529,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
                 if (gidx >= 0) {
                     const uint32_t didx = fdiv((uint32_t)gidx, a.div_cap);
                     const uint32_t fidx = (uint32_t)gidx - didx * (uint32_t)g.cache_capacity;
-                    src[u] = reinterpret_cast<const VT*>(g.cache[didx] + (int64_t)fidx * g.F) + ch;
+                    const float* chunk = g.shard_tab[didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
+                    src[u] = reinterpret_cast<const VT*>(chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * g.F) + ch;
                 } else if (id >= 0) {
                     src[u] = reinterpret_cast<const VT*>(g.table + (int64_t)(id % g.total_num_nodes) * g.F) + ch;
                 }
@@ -605,12 +606,12 @@ __global__ void k_build_topo_map(int8_t* owner, int32_t* row, const int32_t* QT,
     }
 }
 // FeatFillUp (GPUCache.cu:200-205): cache row r of clique GPU Ki = features of QF[r*Kg + Ki]
-__global__ void k_feat_fill_up(int32_t capacity, int32_t F, float* cache, const float* table, const int32_t* QF,
-                               int32_t Kg, int32_t Ki, int32_t V)
+__global__ void k_feat_fill_up(int32_t row0, int32_t rows, int32_t F, float* cache, const float* table,
+                               const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V)
 {
-    const int64_t n = (int64_t)capacity * F;
+    const int64_t n = (int64_t)rows * F;
     for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = i / F, t = r * Kg + Ki;
+        const int64_t r = row0 + i / F, t = r * Kg + Ki;
         if (t >= V) continue;
         cache[i] = table[(int64_t)QF[t] * F + i % F];
     }
@@ -765,9 +766,8 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     GatherKArgs a;
     a.g = g;
     a.div_cap = FastDiv((uint32_t)(g.cache_capacity > 0 ? g.cache_capacity : 1));
+    // cache chunks are hipMalloc'ed (256-byte aligned) and hold whole rows: F % 4 == 0 keeps rows 16-byte aligned
     bool vec4 = (g.F % 4 == 0) && (((uintptr_t)g.table | (uintptr_t)g.dst) % 16 == 0);
-    for (int i = 0; vec4 && i < kMaxParts; i++)
-        if (g.cache[i] && ((uintptr_t)g.cache[i] % 16)) vec4 = false;
     const int C = vec4 ? g.F / 4 : g.F;
     if ((int64_t)rows_bound * C >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);
@@ -832,11 +832,11 @@ void launch_build_topo_map(hipStream_t s, int8_t* owner, int32_t* row, const int
     k_build_topo_map<<<grid_for((int64_t)capacity * Kg, 256), 256, 0, s>>>(owner, row, QT, capacity, Kg, Ki, V);
     HIP_CHECK_LAST();
 }
-void launch_feat_fill_up(hipStream_t s, int32_t capacity, int32_t F, float* cache, const float* table, const int32_t* QF,
-                         int32_t Kg, int32_t Ki, int32_t V)
+void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, float* chunk, const float* table,
+                         const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V)
 {
-    if (capacity <= 0) return;
-    k_feat_fill_up<<<grid_for((int64_t)capacity * F, 256), 256, 0, s>>>(capacity, F, cache, table, QF, Kg, Ki, V);
+    if (rows <= 0) return;
+    k_feat_fill_up<<<grid_for((int64_t)rows * F, 256), 256, 0, s>>>(row0, rows, F, chunk, table, QF, Kg, Ki, V);
     HIP_CHECK_LAST();
 }
 void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,

@@ -131,7 +131,7 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return; }
     GatherArgs g;
     g.table = noder->float_attrs;
-    for (int i = 0; i < kMaxParts; i++) g.cache[i] = nullptr;
+    g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1;
     g.feat_map = nullptr;
     g.cache_capacity = 1;
     g.F = F;
@@ -142,11 +142,14 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     g.off_idx = off_idx;
     g.size_idx = size_idx;
     g.dst_rows = p->feature_rows;
-    if (cache && dev_id >= 0 && dev_id < cache->device_count && cache->ctl[dev_id]->feat_map && cache->ctl[dev_id]->node_capacity > 0) {
-        const int Kg = cache->Kg, Ki = dev_id / Kg;
+    if (cache && dev_id >= 0 && dev_id < cache->device_count && cache->ctl[dev_id]->feat_map && cache->ctl[dev_id]->node_capacity > 0 &&
+        cache->d_shard_tab[dev_id]) {
+        const int Ki = dev_id / cache->Kg;
         g.feat_map = cache->ctl[dev_id]->feat_map;
         g.cache_capacity = cache->ctl[dev_id]->node_capacity;
-        for (int j = 0; j < Kg; j++) g.cache[j] = cache->float_feature_cache[Ki * Kg + j]; // d_float_feature_cache_ptr_, GPUCache.cu:809-816
+        g.shard_tab = cache->d_shard_tab[dev_id]; // d_float_feature_cache_ptr_, GPUCache.cu:788-816
+        g.chunk_shift = cache->chunk_shift[Ki];
+        g.nchunks = cache->nchunks[Ki];
     }
     if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return; }
     launch_gather((hipStream_t)strm_hdl, g, rows_bound);

@@ -200,8 +200,13 @@ def test_operator_plugin_api(K, oracle, small_ds):
 # ---------------------------------------------------------------------------------------------------
 # cache: pre-sampling, ranking, cost model, fill-up, unified cache with Kg logical GPUs on one device
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("G,mode", [(1, 0), (2, 1), (4, 2), (4, 1)])
-def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode):
+@pytest.mark.parametrize("G,mode,chunk_bytes", [(1, 0, None), (2, 1, None), (4, 2, 65536), (4, 1, 40000)])
+def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, monkeypatch):
+    # chunk_bytes: force the cache shards to be split into several chunk allocations (default chunk: 1 GiB)
+    if chunk_bytes is not None:
+        monkeypatch.setenv("LEGION_SHARD_CHUNK_BYTES", str(chunk_bytes))
+    else:
+        monkeypatch.delenv("LEGION_SHARD_CHUNK_BYTES", raising=False)
     ds = small_ds
     V, F = ds.spec.V, ds.spec.F
     L = K.lib()
@@ -258,7 +263,10 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode):
             assert np.array_equal(d_pi.to_numpy(np.int8, len(probe)), np.where(probe >= 0, orcs[m].part_index_map[safe], -1))
             assert np.array_equal(d_po.to_numpy(np.int32, len(probe)), np.where(probe >= 0, orcs[m].part_offset_map[safe], -1))
             j = m - Ki * Kg
-            cache_rows = K.read_dev(L.GPUCache_Float_Feature_Cache(eng.cache, m), np.float32, cm["node_capacity"] * F).reshape(-1, F)
+            rpc, nch = L.GPUCache_ShardChunkRows(eng.cache, m), L.GPUCache_ShardChunkCount(eng.cache, m)
+            assert nch == (cm["node_capacity"] + rpc - 1) // rpc and (nch > 1) == (chunk_bytes is not None)
+            cache_rows = np.concatenate([K.read_dev(L.GPUCache_GetShardChunk(eng.cache, m, q), np.float32,
+                                                    min(rpc, cm["node_capacity"] - q * rpc) * F).reshape(-1, F) for q in range(nch)])
             n_valid = len(range(j, min(V, cm["node_capacity"] * Kg), Kg))
             assert np.array_equal(cache_rows[:n_valid], orcs[m].caches[j][:n_valid])
             fi = K.read_dev(L.GPUGraphStorage_GetFragmentIndex(eng.graph, m, m), np.int64, cm["edge_capacity"] + 1)

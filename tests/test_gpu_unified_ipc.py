@@ -31,7 +31,7 @@ def _worker(rank, world, port, q):
             if p not in sys.path:
                 sys.path.insert(0, p)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          HSA_ENABLE_IPC_MODE_LEGACY="0")
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_SHARD_CHUNK_BYTES="200000")   # 4 chunks per shard
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import legion1_amd.capi as K
@@ -69,7 +69,7 @@ def _worker(rank, world, port, q):
         assert np.array_equal(K.read_dev(L.GPUCache_GetQT(eng.cache, 0), np.int32, V), QT)
         # exchange the shards over HIP IPC
         mine = eng.export_shards(rank)
-        assert mine[0] is not None and mine[1] is not None
+        assert mine[0] is not None and len(mine[0]) == L.GPUCache_ShardChunkCount(eng.cache, rank) > 1 and mine[1] is not None
         everyone = D.allgather_object(mine, world)
         for g in range(world):
             if g != rank:

@@ -237,6 +237,10 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                         // final positions are only written by earlier launches: if we see one it is exact,
                         // and k_mark need not probe the table for this slot again
                         if (cur < (((unsigned long long)a.epoch << 32) | kProvisional)) known = (int32_t)(uint32_t)cur;
+                        // a smaller claim of this hop is already in the table: this slot has lost for good
+                        // (claims only decrease).  Point at that slot; if it loses later too, its own aux
+                        // points further, and k_resolve follows the chain to the winner.
+                        else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & 0x7FFFFFFFu);
                         cnt++;
                     } else {
                         dst = -1;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
             c[s] = -1;
-            if (idx < total && aux[idx] < 0) c[s] = cand[idx];
+            if (idx < total && aux[idx] == -1) c[s] = cand[idx]; // known / already lost slots need no probe
         }
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) v[s] = (c[s] >= 0) ? pos_map[c[s]] : 0ull;
@@ -455,8 +459,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(const HopState* __restrict__
 {
     const int32_t base = hs->edge_base, n = hs->n_edges;
     for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int32_t so = agg_src_off[base + i];
-        if (so < -1) agg_src_off[base + i] = aux[-2 - so];
+        int32_t so = agg_src_off[base + i];
+        if (so < -1) {
+            do so = aux[-2 - so]; while (so < -1); // loser -> (earlier loser ->)* winner: short chains
+            agg_src_off[base + i] = so;
+        }
     }
 }
 

@@ -20,6 +20,8 @@
  * which compiles the Thrust headers shipped in this image (rocThrust, host side)
  * and was used to generate tests/golden/rng_kat.json.  Everything else is
  * integer indexing restated line by line; it is "pinned by restatement only".
+ * PARITY vs. the RUNNING reference is therefore UNPINNED beyond the RNG: the reference cannot be built or run in
+ * this image (CUDA-only) and holds no fixture of its own for this path.
  *
  * Plain C99, no dependencies.  Build: see oracle/Makefile.
  */

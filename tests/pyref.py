@@ -2,7 +2,7 @@
 
 Written from the reference sources, not from oracle/legion_oracle.c, so that the two can be
 checked against each other (the reference itself has no tests to pin either).
-Follows Kernels.cu:68-96 (seeds), :112-150 (counters, literal 2-hop code + the H-hop layout of
+Follows Kernels.cu:68-96 (seeds), :112-150 (counters, the 2-hop state machine + the H-hop layout of
 SURVEY 8a), :342-448 (sampler, canonical slot-ascending order), :450-463 (COO offsets),
 :662-702 (feature rows).
 """
@@ -26,7 +26,7 @@ def sample_index(idx: int, deg: int) -> int:
 
 
 def update_counter_reference_2hop(nc, ec, op_id, size):
-    """Literal transcription of update_counter (Kernels.cu:112-150), 2 hops only."""
+    """The reference's 2-hop counter state machine (update_counter, Kernels.cu:112-150) restated in Python."""
     if op_id == 0:
         nc[0] = size; nc[1] = 0; nc[2] = size; nc[3] = 0; nc[4] = size
         ec[0] = 0; ec[1] = 0; ec[2] = 0; ec[3] = 0

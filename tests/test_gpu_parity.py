@@ -423,3 +423,31 @@ def test_link_prediction_seed_batches(K, oracle, synth, small_ds):
         eng.run_batch(0, counter)
         assert_batch_equal(ref, eng.result(0))
     eng.close()
+
+
+def test_five_hops_and_empty_hops(K, oracle):
+    """H = 5 fills the int32[16] counter layout to its last slot (nc[15]); a frontier of degree-0 nodes gives
+    hops with zero slots (only the counters move)."""
+    rng = np.random.RandomState(11)
+    V, F = 300, 4
+    deg = rng.randint(0, 5, size=V)
+    deg[:20] = 0                                   # seeds 0..19: isolated -> every hop of that batch is empty
+    indptr = np.zeros(V + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    indices = rng.randint(0, V, size=int(indptr[-1])).astype(np.int32)
+    feats = rng.rand(V, F).astype(np.float32)
+    labels = rng.randint(0, 3, size=V).astype(np.int32)
+    seeds = np.concatenate([np.arange(20), rng.permutation(np.arange(20, V))[:40]]).astype(np.int32)
+    fan, B = [2, 2, 2, 2, 2], 20
+    orc = oracle.OracleRunner(indptr, indices, feats, V, F, B, fan)
+    eng = make_engine(K, (V, F, indptr, indices, feats), B, fan, seeds=dict(train=[(seeds, labels[seeds])]))
+    for counter in range(3):
+        ref = orc.run_batch(seeds, labels[seeds], counter)
+        eng.run_batch(0, counter)
+        got = eng.result(0)
+        assert_batch_equal(ref, got)
+        if counter == 0:
+            assert got["ec"][7] == 0 and got["nc"][15] == B          # nothing sampled, total == seeds
+        else:
+            assert got["nc"][15] > B
+    eng.close()

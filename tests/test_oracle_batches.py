@@ -160,3 +160,19 @@ def test_link_prediction_seed_layout(oracle, synth, small_ds):
         ref = pyref.run_batch(ds.indptr, ds.indices, ds.features, seeds, lab, B, counter, [5, 3])
         assert_batch_equal(ref, res)
         assert res["ids"][:B].tolist() == seeds[counter * B:(counter + 1) * B].tolist()   # thirds stay in place
+
+
+def test_five_hops_vs_pyref(oracle):
+    rng = np.random.RandomState(5)
+    V, F = 80, 2
+    deg = rng.randint(0, 6, size=V)
+    indptr = np.zeros(V + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    indices = rng.randint(0, V, size=int(indptr[-1])).astype(np.int32)
+    feats = rng.rand(V, F).astype(np.float32)
+    labels = np.zeros(V, np.int32)
+    seeds = rng.permutation(V)[:10].astype(np.int32)
+    fan = [2, 2, 2, 2, 2]
+    res = oracle.OracleRunner(indptr, indices, feats, V, F, 10, fan).run_batch(seeds, labels[seeds], 0)
+    assert_batch_equal(pyref.run_batch(indptr, indices, feats, seeds, labels[seeds], 10, 0, fan), res)
+    assert res["nc"][15] == len(res["ids"]) and res["ec"][7] == len(res["src_off"])

@@ -192,6 +192,9 @@ int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p);
  * entry = (epoch << 32) | value with epoch = 0xFFFFFFFF - batch serial; an entry whose epoch is not
  * the running batch's is "not in the batch"; value < 0x80000000 is the node's index in sampled_ids. */
 uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p);
+/* batches started on this pool (the table epoch is 0xFFFFFFFF - serial); settable to exercise the wrap-around */
+uint32_t GPUMemoryPool_GetBatchSerial(const GPUMemoryPool* p);
+void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial);
 void GPUMemoryPool_Finalize(GPUMemoryPool* p);
 void GPUMemoryPool_Delete(GPUMemoryPool* p);
 

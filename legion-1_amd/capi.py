@@ -103,6 +103,8 @@ _SIGS = {
     "GPUMemoryPool_SetCurrentMode": (None, [vp, i32]),
     "GPUMemoryPool_SetIter": (None, [vp, i32]),
     "GPUMemoryPool_GetPositionMap": (vp, [vp]),
+    "GPUMemoryPool_GetBatchSerial": (u32, [vp]),
+    "GPUMemoryPool_SetBatchSerial": (None, [vp, u32]),
     "GPUMemoryPool_GetAggSrcId": (vp, [vp]),
     "GPUMemoryPool_GetCacheSearchBuffer": (vp, [vp]),
     "GPUMemoryPool_GetTmpPartIdx": (vp, [vp]),

@@ -342,6 +342,8 @@ int32_t* GPUMemoryPool_GetCacheSearchBuffer(const GPUMemoryPool* p) { return p->
 char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p) { return (char*)p->tmp_part_ind; }
 int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p) { return p->tmp_part_off; }
 uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p) { return (uint64_t*)p->pos_map; }
+uint32_t GPUMemoryPool_GetBatchSerial(const GPUMemoryPool* p) { return p->batch_serial; }
+void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial) { p->batch_serial = serial; }
 
 void GPUMemoryPool_Finalize(GPUMemoryPool* p)
 {

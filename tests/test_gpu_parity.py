@@ -451,3 +451,23 @@ def test_five_hops_and_empty_hops(K, oracle):
         else:
             assert got["nc"][15] > B
     eng.close()
+
+
+def test_position_table_epoch_wraparound(K, oracle, small_ds):
+    """The position table is never cleared: entries carry the batch epoch.  Force the epoch counter to its
+    end: the pool wipes the table once and starts over, results stay bit exact across the wrap."""
+    ds = small_ds
+    B, fan = 200, [10, 5]
+    L = K.lib()
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan)
+    eng.run_batch(0, 0)
+    L.GPUMemoryPool_SetBatchSerial(eng.pools[0], 0xFFFFFFF0 - 3)
+    serials = []
+    for it in range(6):
+        ref = orc.run_batch(ds.train, ds.labels[ds.train], it % 3)
+        eng.run_batch(0, it % 3)
+        assert_batch_equal(ref, eng.result(0))
+        serials.append(L.GPUMemoryPool_GetBatchSerial(eng.pools[0]))
+    assert 1 in serials and max(serials) < 0xFFFFFFF0       # wrapped exactly once
+    eng.close()

@@ -248,6 +248,24 @@ def main():
     if world > 1:
         torch.distributed.barrier()   # nobody unmaps a cache shard while a peer may still read it
 
+    # measured streaming-copy rate of this box (float4 copy kernel, read + write bytes), printed beside the vendor peak
+    copy_gbps = None
+    if rank == 0:
+        nbytes = 4 << 30
+        a_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        b_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        e0, e1 = L.d_event_create(), L.d_event_create()
+        L.legion_copy_f4(stream, b_buf.data_ptr(), a_buf.data_ptr(), nbytes)
+        L.d_event_record(e0, stream)
+        for _ in range(5):
+            L.legion_copy_f4(stream, b_buf.data_ptr(), a_buf.data_ptr(), nbytes)
+        L.d_event_record(e1, stream)
+        copy_gbps = round(5 * 2 * nbytes / (L.d_event_elapsed_ms(e0, e1) * 1e-3) / 1e9, 1)
+        del a_buf, b_buf
+        if roofline is not None:
+            roofline["measured_copy_GBps"] = copy_gbps
+            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbps, 4)
+
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
         cpu_baseline = run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail)

@@ -305,6 +305,9 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
     int cur = 0;
     HIP_CHECK(hipGetDevice(&cur));
     c->device = device_id >= 0 ? device_id : cur;
+    // $LEGION_IPC_DEVICE: logical GPU (row of the shm handle table) when it differs from the physical device,
+    // e.g. several logical GPUs of a clique exercised on one physical device
+    if (device_id < 0 && getenv("LEGION_IPC_DEVICE")) c->device = atoi(getenv("LEGION_IPC_DEVICE"));
     c->shm = (volatile shmStruct*)shm_map(sizeof(shmStruct), &c->shm_fd);
     if (!c->shm) { printf("Failed to create shared memory slab\n"); delete c; LEGION_ARG_ERROR("legion_ipc_client_open: shm"); return nullptr; }
     for (int i = 0; i < 3; i++) c->steps[i] = c->shm->steps[i];

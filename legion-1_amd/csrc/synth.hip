@@ -72,10 +72,21 @@ __global__ void k_synth_seed_ids(int32_t* out, int64_t i0, int64_t n, uint32_t V
     }
 }
 
-__global__ void k_copy_f4(float4* __restrict__ dst, const float4* __restrict__ src, int64_t n)
+typedef float copy_v4f __attribute__((ext_vector_type(4)));
+// streaming copy: 4 independent 16-byte non-temporal loads in flight per lane, non-temporal stores
+__global__ __launch_bounds__(256) void k_copy_f4(copy_v4f* __restrict__ dst, const copy_v4f* __restrict__ src, int64_t n)
 {
-    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = src[i];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        copy_v4f a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        copy_v4f c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 } // namespace legion
@@ -128,7 +139,7 @@ void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes)
 {
     const int64_t n = bytes / 16;
     if (n <= 0) return;
-    k_copy_f4<<<2048, 256, 0, (hipStream_t)stream>>>((float4*)dst, (const float4*)src, n);
+    k_copy_f4<<<2048, 256, 0, (hipStream_t)stream>>>((copy_v4f*)dst, (const copy_v4f*)src, n);
     HIP_CHECK_LAST();
 }
 

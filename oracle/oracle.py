@@ -174,6 +174,9 @@ class OracleRunner:
 
     def run_batch(self, all_ids, all_labels, counter, mode=0, is_presc=False, gather=True, batch_size=None):
         L = lib()
+        if batch_size is not None and batch_size > self.batch_size:
+            raise ValueError("batch larger than the runner was sized for (the reference sizes its buffers for raw_batch_size; "
+                             "valid/test batches are up to 512, CUDA_IPC_Service.cu:101-117)")
         all_ids = np.ascontiguousarray(all_ids, dtype=np.int32)
         all_labels = np.ascontiguousarray(all_labels, dtype=np.int32)
         self._keep = []

@@ -79,3 +79,58 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac)
         assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
     text = open(log).read()
     assert "Train Steps: %d" % steps[0] in text and "Server Stopped" in text
+
+
+def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
+    """`legion 2 1`: two logical GPUs in ONE server process (a thread per GPU, Server.cu:119-127), Kg = 2 unified
+    cache with in-kernel peer reads (both logical GPUs map onto the box's single device), one trainer process
+    per GPU.  Each trainer must see exactly its partition's batches (tid % 2 split, GPUGraphStore.cu:332-346)."""
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    data = str(tmp_path / "ds") + "/"
+    synth.write_legion_files(ds, data)
+    B, epochs, fan, G = 512, 1, [10, 5], 2    # >= 512: valid/test batches are up to 512 seeds (CUDA_IPC_Service.cu:101-117)
+    budget = int(spec.V * spec.F * 4 * 0.1)
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write(synth.meta_config_line(ds, data, B, budget, epochs, 0))
+    ns = "g2_%d_" % os.getpid()
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([SERVER, str(G), "1", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,
+                                  env=env, cwd=str(tmp_path))
+    clients = []
+    try:
+        _wait_ready(server, log)
+        for g in range(G):
+            out = str(tmp_path / ("client%d.json" % g))
+            clients.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_client.py"), str(spec.F), str(epochs), out],
+                                                  env=dict(env, LEGION_IPC_DEVICE=str(g)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for out, c in clients:
+            stdout, _ = c.communicate(timeout=300)
+            assert c.returncode == 0, stdout[-3000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        for _, c in clients:
+            if c.poll() is None:
+                c.kill()
+        if server.poll() is None:
+            server.kill()
+    parts = {0: oracle.split_seeds(ds.train, G), 1: oracle.split_seeds(ds.valid, G), 2: oracle.split_seeds(ds.test, G)}
+    steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)
+    assert "xGMI Clique: 1 GPU Per Clique: 2" in open(log).read()
+    H = len(fan)
+    for g in range(G):
+        got = json.load(open(clients[g][0]))
+        assert got["steps"] == steps.tolist() and len(got["batches"]) == oracle.max_step(steps, epochs)
+        bs = {0: int(tb[g]), 1: int(vb[g]), 2: int(sb[g])}
+        orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+        for rec in got["batches"]:
+            mode, local = oracle.schedule(steps, epochs, rec["b"])
+            ids = parts[mode][g]
+            ref = orc.run_batch(ids, ds.labels[ids], local, mode=mode, batch_size=bs[mode])
+            assert rec["n"] == ref["nc"][5 + 2 * H]
+            assert rec["ids"] == sha(ref["ids"]) and rec["features"] == sha(ref["features"]) and rec["labels"] == sha(ref["labels"])
+            assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])

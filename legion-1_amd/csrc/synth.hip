@@ -139,7 +139,8 @@ void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes)
 {
     const int64_t n = bytes / 16;
     if (n <= 0) return;
-    k_copy_f4<<<2048, 256, 0, (hipStream_t)stream>>>((copy_v4f*)dst, (const copy_v4f*)src, n);
+    // 32 k workgroups measured fastest on MI355X (5.3 TB/s for 2 x 4 GiB; 2048: 4.7, torch copy_: 4.8)
+    k_copy_f4<<<32768, 256, 0, (hipStream_t)stream>>>((copy_v4f*)dst, (const copy_v4f*)src, n);
     HIP_CHECK_LAST();
 }
 

@@ -30,7 +30,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (/opt/skills/guides/MI355X_MI
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="papers100M", choices=["products", "papers100M", "uk-union"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink V and seed sets (debug only)")
@@ -236,7 +236,7 @@ def main():
             with open(pmc) as f:
                 traffic = json.load(f)["k_gather"]["traffic_bytes_per_launch"]
             traffic_src = "profiles/r01_pmc_hbm_traffic.json"
-        roofline = dict(bound="hbm", kernel="k_gather<float4, 2 in flight, non-temporal>", achieved=round(ach, 1),
+        roofline = dict(bound="hbm", kernel="k_gather<float4, non-temporal>", achieved=round(ach, 1),
                         peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
                         traffic_source=traffic_src, avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),
                         algorithmic_bytes_per_launch=int(gather_bytes.mean()),

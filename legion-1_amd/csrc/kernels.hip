@@ -778,12 +778,14 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     const int C = vec4 ? g.F / 4 : g.F;
     if ((int64_t)rows_bound * C >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);
-    // Tuned on MI355X (profiles/r01_gather_sweep.md): 2 chunks in flight per lane, non-temporal loads and
-    // stores (rows are read once and written once: keep them out of L2/MALL), 8 workgroups per CU.
-    constexpr int U = 2;
-    const int grid = grid_for((int64_t)rows_bound * C, kBlock * U, 8);
-    if (vec4) k_gather<v4f, U, 2><<<grid, kBlock, 0, s>>>(a);
-    else k_gather<float, U, 2><<<grid, kBlock, 0, s>>>(a);
+    // Tuned on MI355X (profiles/r01_gather_sweep.md): non-temporal loads and stores (rows are read once and
+    // written once: keep them out of L2/MALL).
+    // One 16-byte chunk per lane and iteration, up to 512 workgroups per CU (131 072): the launch is sized
+    // by the static row bound, of which a batch typically fills 15-20 %, so a workgroup runs ~2 iterations.
+    // Measured best on MI355X (profiles/r01_gather_sweep.md): 333 us vs 340-365 us for 2048 persistent workgroups.
+    const int grid = grid_for((int64_t)rows_bound * C, kBlock, 512);
+    if (vec4) k_gather<v4f, 1, 2><<<grid, kBlock, 0, s>>>(a);
+    else k_gather<float, 1, 2><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
 }
 

@@ -34,7 +34,10 @@ struct DeviceGuard {
 // ---- constants --------------------------------------------------------------------------------
 constexpr uint32_t kUnseen = 0xFFFFFFFFu;      // position-table value: node not in the batch
 constexpr uint32_t kProvisional = 0x80000000u; // | slot idx : claimed in the running hop
-constexpr int kTile = 1024;                    // sampler slots per workgroup tile
+#ifndef LEGION_KTILE
+#define LEGION_KTILE 1024
+#endif
+constexpr int kTile = LEGION_KTILE;            // sampler slots per workgroup tile
 constexpr int kBlock = 256;                    // threads per workgroup
 constexpr int kMaxParts = LEGION_MAX_DEVICE;
 

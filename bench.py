@@ -129,7 +129,7 @@ def main():
     empty = (np.zeros(0, np.int32), np.zeros(0, np.int32))
     seeds = dict(train=[((mine.data_ptr(), n_mine), (my_labels.data_ptr(), n_mine)) if g == me else empty for g in range(G)])
     overlap = args.pipeline == "overlap" and args.gather == "all"
-    depth = 2 if overlap else 1
+    depth = 2      # the reference's PIPELINE_DEPTH; the serial schedule only uses pipe 0
     eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=G,
                    csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E, pipeline_depth=depth,
                    local_devs=[me], train_step=max(1, args.presc_steps))
@@ -140,7 +140,7 @@ def main():
     else:
         L.GPUCache_SetPreSc(eng.cache, 0)  # steady state: no pre-sampling epoch in the all-resident configuration
     stream = L.d_stream_create()       # sampler stream
-    gstream = L.d_stream_create() if overlap else stream   # gather stream (reference: streams_[1], Server.cu:178-181)
+    gstream2 = L.d_stream_create()     # gather stream of the overlapped schedule (reference: streams_[1], Server.cu:178-181)
     steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
     K_steps, W = args.steps, args.warmup
 
@@ -152,12 +152,13 @@ def main():
     ev_gathered = [L.d_event_create() for _ in range(depth)]  # gather of the batch in pipe q is complete
     used = [False] * depth
 
-    def step(i, timed_idx=None):
+    def step(i, timed_idx=None, overlap=overlap):
         """One mini-batch.  overlap: depth-2 pipes (the reference's PIPELINE_DEPTH), the sampler of batch
         i+1 runs on `stream` while the gather of batch i runs on `gstream`; a pipe's buffers are reused
         only after its gather finished."""
         it = i % steps_avail
-        q = i % depth
+        q = i % depth if overlap else 0
+        gstream = gstream2 if overlap else stream
         o = eng.out[me][q]
         L.GPUMemoryPool_SetCurrentPipe(pool, q)
         L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
@@ -189,8 +190,7 @@ def main():
 
     def drain():
         L.d_stream_sync(stream)
-        if overlap:
-            L.d_stream_sync(gstream)
+        L.d_stream_sync(gstream2)
         torch.cuda.synchronize()
 
     for i in range(W):
@@ -222,6 +222,23 @@ def main():
     import legion1_amd.dist as D
     elapsed_max, (job_edges, job_nodes, job_bytes) = D.aggregate(
         elapsed, [tot_edges, tot_nodes, float(samp_bytes.sum() + gather_bytes.sum())], world, device=dev)
+
+    # the other schedule on the very same K batches (reported beside the headline, never instead of it)
+    alt = None
+    if not per_level:
+        if world > 1:
+            torch.distributed.barrier()
+        t_alt = time.perf_counter()
+        for i in range(K_steps):
+            step(W + i, overlap=not overlap)
+        drain()
+        alt_elapsed = time.perf_counter() - t_alt
+        if world > 1:
+            torch.distributed.barrier()
+        alt_max, _ = D.aggregate(alt_elapsed, [0.0], world, device=dev)
+        alt = {"pipeline": "serial" if overlap else "overlap", "ms_per_step": round(alt_max / K_steps * 1e3, 4),
+               "value": round(job_edges / alt_max, 1), "unit": "edges/s",
+               "pipeline_frac": round(job_bytes / alt_max / 1e9 / (HBM_PEAK_GBPS * world), 4)}
 
     # dominant kernel (k_gather: it moves ~94 % of the batch's algorithmic bytes), HIP events on its stream
     roofline = None
@@ -292,6 +309,7 @@ def main():
             "edges_per_batch": round(job_edges / (K_steps * world), 1),
             "unique_nodes_per_batch": round(job_nodes / (K_steps * world), 1),
             "graph_gen_s": round(gen_s, 2),
+            "alt_schedule": alt,
             "cache": {"mode": args.cache, **(cache_info or {}), **(xgmi or {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -37,8 +37,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10,5")
     ap.add_argument("--gather", default="all", choices=["all", "level"], help="one gather per batch or one per level")
-    ap.add_argument("--pipeline", default="serial", choices=["overlap", "serial"],
-                    help="overlap: gather of batch i on a second stream while batch i+1 is sampled (depth-2 pipes)")
+    ap.add_argument("--pipeline", default="serial", choices=["overlap", "serial", "intra"],
+                    help="serial: one stream.  intra: the reference's two-stream schedule inside a batch (Server.cu:301-328): "
+                         "the rows of level l are gathered on a second stream while hop l+1 is sampled; the last level runs alone.  "
+                         "overlap: whole-batch gather of batch i on a second stream while batch i+1 is sampled (depth-2 pipes)")
     ap.add_argument("--cache", default="replicated", choices=["replicated", "unified"],
                     help="replicated: every GPU holds all features (Kg=1).  unified: the clique-wide hotness-partitioned "
                          "feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
@@ -129,6 +131,7 @@ def main():
     empty = (np.zeros(0, np.int32), np.zeros(0, np.int32))
     seeds = dict(train=[((mine.data_ptr(), n_mine), (my_labels.data_ptr(), n_mine)) if g == me else empty for g in range(G)])
     overlap = args.pipeline == "overlap" and args.gather == "all"
+    intra = args.pipeline == "intra"
     depth = 2      # the reference's PIPELINE_DEPTH; the serial schedule only uses pipe 0
     eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=G,
                    csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E, pipeline_depth=depth,
@@ -144,7 +147,10 @@ def main():
     steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
     K_steps, W = args.steps, args.warmup
 
-    per_level = args.gather == "level"
+    per_level = args.gather == "level" and not intra
+    ev_hop = [L.d_event_create() for _ in range(H + 1)]   # intra: hop h of the running batch is complete
+    ev_gdone = L.d_event_create()                          # intra: every gather of the running batch is complete
+    intra_started = [False]
     log = K.DevBuf((K_steps + W) * 128)  # nc/ec of every step, copied on-stream
     ev = [(L.d_event_create(), L.d_event_create()) for _ in range(K_steps)]
     pool = eng.pools[me]
@@ -159,6 +165,8 @@ def main():
         it = i % steps_avail
         q = i % depth if overlap else 0
         gstream = gstream2 if overlap else stream
+        if intra and not overlap:
+            return step_intra(i, it, timed_idx)
         o = eng.out[me][q]
         L.GPUMemoryPool_SetCurrentPipe(pool, q)
         L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
@@ -185,6 +193,35 @@ def main():
             if overlap:
                 L.d_event_record(ev_gathered[q], gstream)
                 used[q] = True
+        L.make_update_plan(stream, eng.graph, eng.cache, pool, me, K.TRAINMODE)
+        L.update_cache(stream, eng.cache, eng.noder, pool, me, K.TRAINMODE)
+
+    def step_intra(i, it, timed_idx):
+        """The reference's schedule inside one batch: FeatureExtractor ops on the second stream behind the event of
+        the op that produced their rows (Server.cu:309-316); the next batch starts when the last gather is done."""
+        o = eng.out[me][0]
+        L.GPUMemoryPool_SetCurrentPipe(pool, 0)
+        L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        if intra_started[0]:
+            L.d_stream_wait_event(stream, ev_gdone)
+        L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, it, me, me, K.TRAINMODE)
+        L.d_event_record(ev_hop[0], stream)
+        L.d_stream_wait_event(gstream2, ev_hop[0])
+        L.get_feature_kernel(gstream2, eng.cache, eng.noder, pool, me, 1, 1)
+        for h in range(H):
+            L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
+            L.d_event_record(ev_hop[h + 1], stream)
+            L.d_stream_wait_event(gstream2, ev_hop[h + 1])
+            last = h == H - 1
+            if last and timed_idx is not None:
+                L.d_event_record(ev[timed_idx][0], gstream2)
+            L.get_feature_kernel(gstream2, eng.cache, eng.noder, pool, me, 2 * h + 3, 1)
+            if last and timed_idx is not None:
+                L.d_event_record(ev[timed_idx][1], gstream2)
+        L.d_event_record(ev_gdone, gstream2)
+        intra_started[0] = True
+        L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
+        L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
         L.make_update_plan(stream, eng.graph, eng.cache, pool, me, K.TRAINMODE)
         L.update_cache(stream, eng.cache, eng.noder, pool, me, K.TRAINMODE)
 
@@ -225,7 +262,7 @@ def main():
 
     # the other schedule on the very same K batches (reported beside the headline, never instead of it)
     alt = None
-    if not per_level:
+    if not per_level and not intra:
         if world > 1:
             torch.distributed.barrier()
         t_alt = time.perf_counter()
@@ -244,10 +281,14 @@ def main():
     roofline = None
     if not per_level:
         g_ms = np.array([L.d_event_elapsed_ms(a, b) for a, b in ev], dtype=np.float64)
-        ach = float(gather_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
+        if intra:   # the timed launches are the last level's gather: its rows are the new nodes of hop H
+            gather_launch_bytes = u_h[H - 1] * (8 * F + 8)
+        else:
+            gather_launch_bytes = gather_bytes
+        ach = float(gather_launch_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and not unified and os.path.exists(pmc):
+        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and not unified and not intra and os.path.exists(pmc):
             # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
             # command (counters cannot be read from inside the process); gfx950 FETCH_SIZE x2 correction applied
             with open(pmc) as f:
@@ -256,7 +297,8 @@ def main():
         roofline = dict(bound="hbm", kernel="k_gather<float4, non-temporal>", achieved=round(ach, 1),
                         peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
                         traffic_source=traffic_src, avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),
-                        algorithmic_bytes_per_launch=int(gather_bytes.mean()),
+                        algorithmic_bytes_per_launch=int(gather_launch_bytes.mean()),
+                        launch="last level (hop %d rows) of the per-level gathers" % H if intra else "all rows of the batch",
                         pipeline_frac=round(job_bytes / elapsed_max / 1e9 / (HBM_PEAK_GBPS * world), 4))
 
     xgmi = None

@@ -88,8 +88,10 @@ IPCEnv* NewIPCEnv(int32_t device_count)
     std::cout << "start initialize ipc env\n";
     e->shm = (volatile shmStruct*)shm_map(sizeof(shmStruct), &e->shm_fd);
     if (!e->shm) {
-        printf("Failed to create shared memory slab\n");
-        if (true) { delete e; LEGION_ARG_ERROR("NewIPCEnv: shm_open/mmap failed"); return nullptr; }
+        printf("Failed to create shared memory slab\n"); // reference: exit(EXIT_FAILURE) (CUDA_IPC_Service.cu:46-48)
+        delete e;
+        LEGION_ARG_ERROR("NewIPCEnv: shm_open/mmap failed");
+        return nullptr;
     }
     std::cout << "Shared Memory Opened\n";
     // $LEGION_IPC_ATTACH=1: another server process of this job already created the slab

@@ -228,7 +228,7 @@ public:
         record(params);
     }
 private:
-    int op_id_;
+    [[maybe_unused]] int op_id_;
 };
 
 class Random_Sampler : public Operator { // Operator.cu:37-55
@@ -241,7 +241,7 @@ public:
         record(params);
     }
 private:
-    int op_id_;
+    [[maybe_unused]] int op_id_;
 };
 
 class Feature_Extractor : public Operator { // Operator.cu:61-76 (records no event)
@@ -253,7 +253,7 @@ public:
                            (GPUMemoryPool*)params->memorypool, params->device_id, op_id_, params->in_memory);
     }
 private:
-    int op_id_;
+    [[maybe_unused]] int op_id_;
 };
 
 class Cache_Planner : public Operator { // Operator.cu:82-97
@@ -268,7 +268,7 @@ public:
         record(params);
     }
 private:
-    int op_id_;
+    [[maybe_unused]] int op_id_;
 };
 
 class Cache_Updater : public Operator { // Operator.cu:103-119
@@ -283,7 +283,7 @@ public:
         record(params);
     }
 private:
-    int op_id_;
+    [[maybe_unused]] int op_id_;
 };
 
 } // namespace

@@ -471,3 +471,48 @@ def test_position_table_epoch_wraparound(K, oracle, small_ds):
         serials.append(L.GPUMemoryPool_GetBatchSerial(eng.pools[0]))
     assert 1 in serials and max(serials) < 0xFFFFFFF0       # wrapped exactly once
     eng.close()
+
+
+def test_overlapped_two_stream_schedule(K, oracle, small_ds):
+    """bench.py's --pipeline overlap: sampler of batch i+1 on one stream while the gather of batch i runs on a
+    second stream, depth-2 pipes, a pipe reused only after its gather finished.  Every batch must still be
+    bit exact (the schedules differ in timing only)."""
+    ds = small_ds
+    B, fan = 300, [10, 5, 3]
+    H = len(fan)
+    L = K.lib()
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan, pipeline_depth=2)
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    pool = eng.pools[0]
+    s_samp, s_gath = L.d_stream_create(), L.d_stream_create()
+    ev_sampled = [L.d_event_create(), L.d_event_create()]
+    ev_gathered = [L.d_event_create(), L.d_event_create()]
+    used = [False, False]
+
+    def enqueue(i):
+        q = i % 2
+        L.GPUMemoryPool_SetCurrentPipe(pool, q)
+        L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        if used[q]:
+            L.d_stream_wait_event(s_samp, ev_gathered[q])
+        L.batch_generator_kernel(s_samp, eng.noder, eng.cache, pool, B, i, 0, 0, K.TRAINMODE)
+        for h in range(H):
+            L.GPU_Random_Sampling(s_samp, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
+        L.d_event_record(ev_sampled[q], s_samp)
+        L.d_stream_wait_event(s_gath, ev_sampled[q])
+        L.get_feature_kernel_all(s_gath, eng.cache, eng.noder, pool, 0, 1)
+        L.d_event_record(ev_gathered[q], s_gath)
+        used[q] = True
+        L.make_update_plan(s_samp, eng.graph, eng.cache, pool, 0, K.TRAINMODE)
+
+    n = 6
+    enqueue(0)
+    for i in range(n):
+        if i + 1 < n:
+            enqueue(i + 1)          # batch i+1 is sampled while batch i is still being gathered
+        L.d_stream_sync(s_samp)
+        L.d_stream_sync(s_gath)
+        K.check()
+        assert_batch_equal(orc.run_batch(ds.train, ds.labels[ds.train], i), eng.result(0, pipe=i % 2))
+    eng.close()

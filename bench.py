@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--cache", default="replicated", choices=["replicated", "unified"],
                     help="replicated: every GPU holds all features (Kg=1).  unified: the clique-wide hotness-partitioned "
                          "feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
+    ap.add_argument("--table", default="device", choices=["device", "host"],
+                    help="where the V x F feature table lives: HBM (default) or pinned host memory read over PCIe -- the "
+                         "reference's UVA configuration (GPUGraphStore.cu:315); combine with --cache unified for an HBM cache")
     ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
@@ -113,6 +116,16 @@ def main():
     V, F = spec.V, spec.F
     t0 = time.time()
     indptr, indices, feats, E = build_graph_on_gpu(K, spec, dev)
+    feat_ptr, feat_loc, host_table = feats.data_ptr(), K.LOC_DEVICE, None
+    if args.table == "host":   # move the table to pinned, device-mapped host memory; misses then cross PCIe
+        nbytes = V * F * 4
+        host_table = L.host_alloc_space64(nbytes)
+        L.d_copy_d_2_h(host_table, feats.data_ptr(), nbytes)
+        K.check()
+        del feats
+        feats = None
+        torch.cuda.empty_cache()
+        feat_ptr, feat_loc = host_table, K.LOC_HOST_PINNED
     # seeds of this rank: train ids with tid % world == rank, labels from the generator
     all_train = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
     L.legion_synth_seed_ids(None, all_train.data_ptr(), 0, spec.n_train, V, spec.M2, spec.C2, 1, 0)
@@ -133,8 +146,8 @@ def main():
     overlap = args.pipeline == "overlap" and args.gather == "all"
     intra = args.pipeline == "intra"
     depth = 2      # the reference's PIPELINE_DEPTH; the serial schedule only uses pipe 0
-    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), V, F, seeds, B, fan, G=G,
-                   csr_location=K.LOC_DEVICE, features_location=K.LOC_DEVICE, E=E, pipeline_depth=depth,
+    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feat_ptr, V, F, seeds, B, fan, G=G,
+                   csr_location=K.LOC_DEVICE, features_location=feat_loc, E=E, pipeline_depth=depth,
                    local_devs=[me], train_step=max(1, args.presc_steps))
     eng.alloc_features()
     cache_info = None
@@ -288,7 +301,7 @@ def main():
         ach = float(gather_launch_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and not unified and not intra and os.path.exists(pmc):
+        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and not unified and not intra and args.table == "device" and os.path.exists(pmc):
             # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
             # command (counters cannot be read from inside the process); gfx950 FETCH_SIZE x2 correction applied
             with open(pmc) as f:
@@ -327,6 +340,9 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
+        if host_table is not None:   # the table already is host memory: view it, no copy
+            import ctypes
+            feats = np.ctypeslib.as_array(ctypes.cast(host_table, ctypes.POINTER(ctypes.c_float)), shape=(V, F))
         cpu_baseline = run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail)
 
     if rank == 0:
@@ -343,7 +359,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int32 ids / f32 rows (verbatim copy)",
             "data": "synthetic",
-            "config": {"workload": f"{spec.name}-shape synthetic graph, {H}-hop fan-out {fan}, batch {B}, CSR + features resident in HBM" + (" (Kg=1 replicas)" if not unified else f", unified feature cache over the {world}-GPU clique"),
+            "config": {"workload": f"{spec.name}-shape synthetic graph, {H}-hop fan-out {fan}, batch {B}, CSR " + ("+ features resident in HBM" if args.table == "device" else "in HBM, features in pinned host memory (PCIe zero-copy)") + (" (Kg=1 replicas)" if not unified else f", unified feature cache over the {world}-GPU clique"),
                        "V": V, "E": E, "F": F, "batch": B, "fanout": fan, "gather": args.gather, "pipeline": args.pipeline if args.gather == "all" else "serial", "seeds_per_rank": n_mine,
                        "parallelism": f"dp{world} (seed shards tid % {world}, no data-path collective)"},
             "feature_GBps": round(job_nodes * 4 * F / elapsed_max / 1e9, 2),
@@ -424,7 +440,7 @@ def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan
     h_indptr = indptr.cpu().numpy()
     h_indices = indices.cpu().numpy()
     with_feat = not args.no_cpu_features
-    h_feats = feats.cpu().numpy() if with_feat else None
+    h_feats = (feats if isinstance(feats, np.ndarray) else feats.cpu().numpy()) if with_feat else None
     h_ids = mine.cpu().numpy()
     h_lab = my_labels.cpu().numpy()
     copy_s = time.time() - t0

@@ -268,17 +268,19 @@ void Server_Initialize(Server* s, int global_shard_count)
     std::cout << "Start load graph\n";
     s->indptr = (int64_t*)host_alloc_space64(((int64_t)V + 1) * 8);
     s->indices = (int32_t*)host_alloc_space64(m.edge_num * 4);
-    read_file(m.dataset_path + "edge_src", s->indptr, ((int64_t)V + 1) * 8);
-    read_file(m.dataset_path + "edge_dst", s->indices, m.edge_num * 4);
+    bool ok = read_file(m.dataset_path + "edge_src", s->indptr, ((int64_t)V + 1) * 8);
+    ok = read_file(m.dataset_path + "edge_dst", s->indices, m.edge_num * 4) && ok;
     std::cout << "start load node\n";
     s->feats = (float*)host_alloc_space64((int64_t)V * F * 4);
-    read_file(m.dataset_path + "features", s->feats, (int64_t)V * F * 4);
+    ok = read_file(m.dataset_path + "features", s->feats, (int64_t)V * F * 4) && ok;
     std::vector<int32_t> training_ids(m.training_set_num), validation_ids(m.validation_set_num), testing_ids(m.testing_set_num),
         all_labels(V), partition_index(V);
-    read_file(m.dataset_path + "trainingset", training_ids.data(), (int64_t)m.training_set_num * 4);
-    read_file(m.dataset_path + "validationset", validation_ids.data(), (int64_t)m.validation_set_num * 4);
-    read_file(m.dataset_path + "testingset", testing_ids.data(), (int64_t)m.testing_set_num * 4);
-    read_file(m.dataset_path + "labels", all_labels.data(), (int64_t)V * 4);
+    ok = read_file(m.dataset_path + "trainingset", training_ids.data(), (int64_t)m.training_set_num * 4) && ok;
+    ok = read_file(m.dataset_path + "validationset", validation_ids.data(), (int64_t)m.validation_set_num * 4) && ok;
+    ok = read_file(m.dataset_path + "testingset", testing_ids.data(), (int64_t)m.testing_set_num * 4) && ok;
+    ok = read_file(m.dataset_path + "labels", all_labels.data(), (int64_t)V * 4) && ok;
+    // the reference only prints "cannout open file" and carries on with garbage (GPUGraphStore.cu:33-35); fail instead
+    if (!ok) { LEGION_ARG_ERROR("Server_Initialize: dataset file(s) missing"); return; }
     const bool have_part = read_file(m.dataset_path + "partition_" + std::to_string(G) + "_bn", partition_index.data(), (int64_t)V * 4, nullptr, true);
     std::cout << "Finish Reading All Files\n";
     // seed split, GPUGraphStore.cu:332-414

@@ -155,3 +155,20 @@ def test_legion_file_layout(synth, tmp_path):
     assert np.array_equal(np.fromfile(os.path.join(path, "trainingset"), dtype="<i4"), ds.train)
     line = synth.meta_config_line(ds, path, 8000, 1 << 30, 10, 0).split()
     assert len(line) == 11 and int(line[2]) == spec.V and int(line[3]) == ds.E and line[0].endswith("/")
+
+
+def test_launcher_meta_config_line():
+    """launch_server.py writes the launcher contract of legion_server.py:58-59; the expected line is the sample
+    `meta_config` the reference ships at its root (uk-union, 32 GB cache, 10 epochs, clique mode)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("launch_server", os.path.join(ROOT, "legion-1_amd", "launch_server.py"))
+    ls = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ls)
+
+    class A:
+        dataset_path, dataset, train_batch_size, cache_memory, epoch, usenvlink = "/home/atc-artifacts-user/datasets", "UKS", 8000, 32000000000, 10, 1
+    assert ls.meta_line(A) == "/home/atc-artifacts-user/datasets/ukunion/ 8000 133633040 5507679822 256 13363304 100000 100000 32000000000 10 0"
+    assert ls.cache_agg_mode(8, 1) == 1 and ls.cache_agg_mode(1, 1) == 0 and ls.cache_agg_mode(8, 0) == 0
+    assert len(ls.meta_line(A).split()) == 11

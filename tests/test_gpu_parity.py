@@ -516,3 +516,36 @@ def test_overlapped_two_stream_schedule(K, oracle, small_ds):
         K.check()
         assert_batch_equal(orc.run_batch(ds.train, ds.labels[ds.train], i), eng.result(0, pipe=i % 2))
     eng.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_differential(K, oracle, seed):
+    """Random graphs (hubs, isolated nodes, -1 entries, self loops), random fan-outs / batch sizes / hop counts,
+    duplicate and repeated seeds, several consecutive batches on one engine: HIP == oracle, bit for bit."""
+    rng = np.random.RandomState(1000 + seed)
+    V = int(rng.choice([33, 200, 1500, 6000]))
+    F = int(rng.choice([1, 3, 4, 8, 20, 64]))
+    deg = rng.geometric(0.25, size=V) - 1
+    hubs = rng.randint(0, V, size=max(1, V // 100))
+    deg[hubs] = rng.randint(50, 400, size=len(hubs))
+    indptr = np.zeros(V + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    # skewed neighbours: hubs are hit often -> many duplicate claims inside a hop
+    nbr = np.where(rng.rand(int(indptr[-1])) < 0.5, rng.choice(hubs, size=int(indptr[-1])), rng.randint(0, V, size=int(indptr[-1])))
+    nbr[rng.rand(len(nbr)) < 0.02] = -1
+    indices = nbr.astype(np.int32)
+    feats = rng.rand(V, F).astype(np.float32)
+    labels = rng.randint(0, 7, size=V).astype(np.int32)
+    n_seeds = int(rng.randint(5, max(6, min(V, 900))))
+    seeds = rng.randint(0, V, size=n_seeds).astype(np.int32)          # with repetitions
+    hops = int(rng.randint(1, 5))
+    fan = [int(rng.randint(1, 12)) for _ in range(hops)]
+    B = int(rng.randint(1, n_seeds + 1))
+    orc = oracle.OracleRunner(indptr, indices, feats, V, F, B, fan)
+    eng = make_engine(K, (V, F, indptr, indices, feats), B, fan, seeds=dict(train=[(seeds, labels[seeds])]))
+    n_batches = (n_seeds + B - 1) // B
+    for counter in list(range(min(n_batches, 4))) + [0]:
+        ref = orc.run_batch(seeds, labels[seeds], counter)
+        eng.run_batch(0, counter, per_level=bool(rng.randint(2)), plan=bool(rng.randint(2)))
+        assert_batch_equal(ref, eng.result(0))
+    eng.close()

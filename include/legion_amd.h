@@ -123,6 +123,9 @@ GPUGraphStorage* NewGPUMemoryGraphStorage(void);
 void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info);
 void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int32_t Kg, int32_t capacity);
 void GPUGraphStorage_Finalize(GPUGraphStorage* g);
+/* MI355X-first: copy the whole CSR into the HBM of every local GPU (one replica per physical device); the
+ * sampler then reads its own replica instead of the pinned-host table.  Returns bytes per replica (0: nothing done). */
+int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g);
 int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g);
 int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g);
 int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g);
@@ -148,6 +151,8 @@ int32_t* GPUNodeStorage_GetTestingLabels(const GPUNodeStorage* n, int32_t part_i
 int32_t GPUNodeStorage_TrainingSetSize(const GPUNodeStorage* n, int32_t part_id);
 int32_t GPUNodeStorage_ValidationSetSize(const GPUNodeStorage* n, int32_t part_id);
 int32_t GPUNodeStorage_TestingSetSize(const GPUNodeStorage* n, int32_t part_id);
+/* same for the V x F feature table (the backing table of cache misses) */
+int64_t GPUNodeStorage_ReplicateToDevices(GPUNodeStorage* n);
 int32_t GPUNodeStorage_TotalNodeNum(const GPUNodeStorage* n);
 float* GPUNodeStorage_GetAllFloatAttr(const GPUNodeStorage* n);
 int32_t GPUNodeStorage_GetFloatAttrLen(const GPUNodeStorage* n);

@@ -78,6 +78,8 @@ _SIGS = {
     "NewGPUMemoryGraphStorage": (vp, []),
     "GPUGraphStorage_Build": (None, [vp, vp]),
     "GPUGraphStorage_GraphCache": (None, [vp, vp, i32, i32, i32]),
+    "GPUGraphStorage_ReplicateToDevices": (i64, [vp]),
+    "GPUNodeStorage_ReplicateToDevices": (i64, [vp]),
     "GPUGraphStorage_Finalize": (None, [vp]),
     "GPUGraphStorage_Delete": (None, [vp]),
     "GPUGraphStorage_GetFragmentIndex": (vp, [vp, i32, i32]),

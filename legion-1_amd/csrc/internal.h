@@ -168,6 +168,9 @@ struct GPUGraphStorage {
     int64_t edge_num = 0, cache_edge_num = 0;
     int64_t* csr_node_index_cpu = nullptr;   // device-visible pointer of the whole CSR (slot [P])
     int32_t* csr_dst_node_ids_cpu = nullptr;
+    // HBM replicas of the whole CSR, one per logical GPU that has one (GPUGraphStorage_ReplicateToDevices)
+    std::vector<int64_t*> replica_indptr;
+    std::vector<int32_t*> replica_indices;
     int32_t csr_location = LEGION_LOC_HOST_PINNED;
     bool owns_csr = false;
     // fragments per logical GPU (device memory on that GPU's physical device)
@@ -183,6 +186,7 @@ struct GPUGraphStorage {
 struct GPUNodeStorage {
     int32_t partition_count = 0, total_num_nodes = 0, float_attr_len = 0;
     float* float_attrs = nullptr;     // device-visible V x F table
+    std::vector<float*> replica_attrs; // HBM replicas per logical GPU (GPUNodeStorage_ReplicateToDevices)
     int32_t features_location = LEGION_LOC_HOST_PINNED;
     bool owns_features = false;
     std::vector<int32_t> training_set_num, validation_set_num, testing_set_num;

@@ -94,8 +94,9 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     CsrTables csr;
     for (int i = 0; i <= kMaxParts; i++) { csr.indptr[i] = nullptr; csr.indices[i] = nullptr; }
     csr.partition_count = P;
-    csr.indptr[P] = graph->csr_node_index_cpu;
-    csr.indices[P] = graph->csr_dst_node_ids_cpu;
+    // slot [P]: the whole CSR -- this GPU's HBM replica when there is one, else the (pinned host) table
+    csr.indptr[P] = graph->replica_indptr[dev] ? graph->replica_indptr[dev] : graph->csr_node_index_cpu;
+    csr.indices[P] = graph->replica_indices[dev] ? graph->replica_indices[dev] : graph->csr_dst_node_ids_cpu;
     csr.topo_owner = nullptr;
     csr.topo_row = nullptr;
     SamplerBuffers b;
@@ -130,7 +131,7 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     const int q = p->current_pipe;
     if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return; }
     GatherArgs g;
-    g.table = noder->float_attrs;
+    g.table = (dev_id >= 0 && dev_id < noder->partition_count && noder->replica_attrs[dev_id]) ? noder->replica_attrs[dev_id] : noder->float_attrs;
     g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1;
     g.feat_map = nullptr;
     g.cache_capacity = 1;

@@ -321,6 +321,31 @@ void Server_Initialize(Server* s, int global_shard_count)
     GPUNodeStorage_Build(s->noder, &info);
     s->graph = NewGPUMemoryGraphStorage();
     GPUGraphStorage_Build(s->graph, &info);
+    // MI355X-first: 288 GB of HBM usually hold the whole dataset, so replicate the tables into every GPU's HBM
+    // instead of reading them over PCIe (the reference's UVA zero-copy).  $LEGION_TABLES = device | host | auto
+    // (default auto: replicate when CSR + features + 20 % fit into the free HBM of every GPU).
+    {
+        const char* mode = getenv("LEGION_TABLES");
+        const std::string tables = mode ? mode : "auto";
+        const int64_t need = (((int64_t)V + 1) * 8 + m.edge_num * 4 + (int64_t)V * F * 4);
+        bool replicate = tables == "device";
+        if (tables == "auto") {
+            replicate = true;
+            for (int i = 0; i < G; i++) {
+                DeviceGuard guard(i);
+                size_t free_b = 0, total_b = 0;
+                HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+                if ((double)need * 1.2 > (double)free_b) replicate = false;
+            }
+        }
+        if (replicate) {
+            GPUGraphStorage_ReplicateToDevices(s->graph);
+            GPUNodeStorage_ReplicateToDevices(s->noder);
+            std::cout << "Tables replicated into HBM: " << need / 1e9 << " GB per GPU\n";
+        } else {
+            std::cout << "Tables stay in pinned host memory (" << need / 1e9 << " GB)\n";
+        }
+    }
     s->cache = NewGPUCache();
     const int32_t train_step = IPCEnv_GetTrainStep(s->env);
     GPUCache_Initialize(s->cache, m.cache_memory, 0, F, train_step, G);

@@ -45,6 +45,36 @@ static T* adopt_table(const T* src, int64_t count, int32_t location, bool* owns)
     return const_cast<T*>(src);
 }
 
+// one HBM replica per distinct physical device among the local logical GPUs
+template <typename T>
+static void replicate_table(const T* src, int64_t count, int32_t P, std::vector<T*>& replica)
+{
+    std::vector<std::pair<int, T*>> per_phys;
+    for (int p = 0; p < P; p++) {
+        if (is_remote_device(p) || replica[p]) continue;
+        const int phys = physical_device(p);
+        T* have = nullptr;
+        for (auto& e : per_phys) if (e.first == phys) have = e.second;
+        if (!have) {
+            DeviceGuard guard(p);
+            HIP_CHECK(hipMalloc(&have, (size_t)count * sizeof(T)));
+            if (have) HIP_CHECK(hipMemcpy(have, src, (size_t)count * sizeof(T), hipMemcpyDefault));
+            per_phys.emplace_back(phys, have);
+        }
+        replica[p] = have;
+    }
+}
+template <typename T>
+static void free_replicas(std::vector<T*>& replica)
+{
+    for (size_t i = 0; i < replica.size(); i++) {
+        if (!replica[i]) continue;
+        T* p = replica[i];
+        for (size_t j = i; j < replica.size(); j++) if (replica[j] == p) replica[j] = nullptr;
+        (void)hipFree(p);
+    }
+}
+
 extern "C" {
 
 // ================================= graph storage ====================================================
@@ -70,6 +100,8 @@ void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info)
     g->frag_indices.assign(P, nullptr);
     g->frag_rows.assign(P, 0);
     g->frag_imported.assign(P, false);
+    g->replica_indptr.assign(P, nullptr);
+    g->replica_indices.assign(P, nullptr);
     g->view_indptr.assign(P, std::vector<int64_t*>(P, nullptr));
     g->view_indices.assign(P, std::vector<int32_t*>(P, nullptr));
 }
@@ -111,9 +143,19 @@ void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int
         }
 }
 
+int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g)
+{
+    if (!g || !g->csr_node_index_cpu || g->csr_location == LEGION_LOC_DEVICE) return 0; // already HBM resident
+    replicate_table<int64_t>(g->csr_node_index_cpu, (int64_t)g->node_num + 1, g->partition_count, g->replica_indptr);
+    replicate_table<int32_t>(g->csr_dst_node_ids_cpu, g->edge_num, g->partition_count, g->replica_indices);
+    return ((int64_t)g->node_num + 1) * 8 + g->edge_num * 4;
+}
+
 void GPUGraphStorage_Finalize(GPUGraphStorage* g)
 {
     if (!g) return;
+    free_replicas(g->replica_indptr);
+    free_replicas(g->replica_indices);
     for (size_t i = 0; i < g->frag_indptr.size(); i++) {
         if (g->frag_imported[i]) {
             if (g->frag_indptr[i]) (void)hipIpcCloseMemHandle(g->frag_indptr[i]);
@@ -208,6 +250,7 @@ void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
         ? adopt_table<float>(info->host_float_attrs, (int64_t)info->total_num_nodes * info->float_attr_len, info->features_location, &owns)
         : nullptr;
     n->owns_features = owns;
+    n->replica_attrs.assign(P, nullptr);
     n->training_set_num.assign(P, 0); n->validation_set_num.assign(P, 0); n->testing_set_num.assign(P, 0);
     n->training_set_ids.assign(P, nullptr); n->validation_set_ids.assign(P, nullptr); n->testing_set_ids.assign(P, nullptr);
     n->training_labels.assign(P, nullptr); n->validation_labels.assign(P, nullptr); n->testing_labels.assign(P, nullptr);
@@ -232,9 +275,17 @@ void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
     }
 }
 
+int64_t GPUNodeStorage_ReplicateToDevices(GPUNodeStorage* n)
+{
+    if (!n || !n->float_attrs || n->features_location == LEGION_LOC_DEVICE) return 0;
+    replicate_table<float>(n->float_attrs, (int64_t)n->total_num_nodes * n->float_attr_len, n->partition_count, n->replica_attrs);
+    return (int64_t)n->total_num_nodes * n->float_attr_len * 4;
+}
+
 void GPUNodeStorage_Finalize(GPUNodeStorage* n)
 {
     if (!n) return;
+    free_replicas(n->replica_attrs);
     auto drop = [](std::vector<int32_t*>& v) { for (auto& p : v) { if (p) (void)hipFree(p); p = nullptr; } };
     drop(n->training_set_ids); drop(n->validation_set_ids); drop(n->testing_set_ids);
     drop(n->training_labels); drop(n->validation_labels); drop(n->testing_labels);

@@ -29,8 +29,8 @@ def _wait_ready(proc, log_path, timeout=240):
     raise AssertionError("server not ready:\n" + open(log_path, errors="ignore").read()[-3000:])
 
 
-@pytest.mark.parametrize("fan,budget_frac", [([25, 10], 0.2), ([5, 4, 3], 10.0)])
-def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac):
+@pytest.mark.parametrize("fan,budget_frac,tables", [([25, 10], 0.2, "host"), ([5, 4, 3], 10.0, "auto"), ([10, 5], 0.1, "device")])
+def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac, tables):
     assert os.path.exists(SERVER), "build the server: make -C legion-1_amd/csrc legion"
     spec = synth.spec_for("products", scale=0.004)
     ds = synth.generate(spec)
@@ -42,7 +42,8 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac)
     with open(meta, "w") as f:
         f.write(synth.meta_config_line(ds, data, B, budget, epochs, 0))
     ns = "t%d_%d_" % (os.getpid(), len(fan))
-    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # LEGION_TABLES: host = the reference's pinned-host tables read over PCIe, device/auto = replicated into HBM
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_TABLES=tables)
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:
         server = subprocess.Popen([SERVER, "1", "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,
@@ -79,6 +80,7 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac)
         assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
     text = open(log).read()
     assert "Train Steps: %d" % steps[0] in text and "Server Stopped" in text
+    assert ("Tables stay in pinned host memory" if tables == "host" else "Tables replicated into HBM") in text
 
 
 def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):

@@ -213,6 +213,7 @@ struct Meta { // ReadMetaFIle, GPUGraphStore.cu:190-223
 
 struct Server {
     int shard_count = 0, train_step = 0, max_step = 0;
+    bool replicated = false;   // CSR + features replicated into every GPU's HBM: the cache has nothing to add
     std::string meta_path = "./meta_config";
     std::vector<int32_t> fanout{25, 10}; // Server.cu:68-69
     Meta meta;
@@ -341,6 +342,7 @@ void Server_Initialize(Server* s, int global_shard_count)
         if (replicate) {
             GPUGraphStorage_ReplicateToDevices(s->graph);
             GPUNodeStorage_ReplicateToDevices(s->noder);
+            s->replicated = true;
             std::cout << "Tables replicated into HBM: " << need / 1e9 << " GB per GPU\n";
         } else {
             std::cout << "Tables stay in pinned host memory (" << need / 1e9 << " GB)\n";
@@ -384,6 +386,8 @@ void Server_PreSc(Server* s, int cache_agg_mode)
     for (auto& th : pool) th.join();
     double t = std::chrono::duration_cast<std::chrono::duration<double>>(std::chrono::steady_clock::now() - t1).count();
     GPUCache_CandidateSelection(s->cache, cache_agg_mode, s->noder, s->graph);
+    // everything already sits in each GPU's HBM: caching would only add an id -> slot indirection (option c)
+    if (s->replicated) GPUCache_SetCapacity(s->cache, 0, 0);
     GPUCache_CostModel(s->cache, cache_agg_mode, s->noder, s->graph, nullptr, s->train_step);
     GPUCache_FillUp(s->cache, cache_agg_mode, s->noder, s->graph);
     std::cout << "First epoch cost: " << t << " s\n";

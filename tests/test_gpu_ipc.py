@@ -97,7 +97,8 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
     with open(meta, "w") as f:
         f.write(synth.meta_config_line(ds, data, B, budget, epochs, 0))
     ns = "g2_%d_" % os.getpid()
-    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # host tables: with HBM replicas the server would (rightly) not build a cache at all
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_TABLES="host")
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:
         server = subprocess.Popen([SERVER, str(G), "1", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,
@@ -122,7 +123,8 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
             server.kill()
     parts = {0: oracle.split_seeds(ds.train, G), 1: oracle.split_seeds(ds.valid, G), 2: oracle.split_seeds(ds.test, G)}
     steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)
-    assert "xGMI Clique: 1 GPU Per Clique: 2" in open(log).read()
+    text = open(log).read()
+    assert "xGMI Clique: 1 GPU Per Clique: 2" in text and "Feat capacity" in text   # the cost model sized a real cache
     H = len(fan)
     for g in range(G):
         got = json.load(open(clients[g][0]))

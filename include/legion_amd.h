@@ -129,10 +129,22 @@ int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g);
 int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g);
 int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g);
 int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g);
-/* fragment of logical GPU part_id as seen from dev_id (NULL when not cached) */
+/* fragment of logical GPU part_id as seen from dev_id (NULL when not cached): FIRST chunk of each array, i.e. the
+ * whole array for fragments below the chunk size (GPU_Memory_Graph_Storage.cu:128-131 d_csr_node_index_/d_csr_dst_node_ids_) */
 int64_t* GPUGraphStorage_GetFragmentIndex(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id);
 int32_t* GPUGraphStorage_GetFragmentMatrix(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id);
-/* HIP-IPC exchange of a clique member's fragment (64-byte handles); returns 0 on success */
+/* A fragment is two lists of chunk allocations (<= $LEGION_SHARD_CHUNK_BYTES, default 1 GiB) so that each piece can be
+ * opened over HIP IPC.  which = 0: indptr, chunk q = entries [q*span, min(rows, (q+1)*span)] (one entry of overlap);
+ * which = 1: indices, chunk q = all rows whose first edge offset o has o / span == q, whole, at element o % span. */
+int32_t GPUGraphStorage_FragmentRows(const GPUGraphStorage* g, int32_t dev_id);
+int64_t GPUGraphStorage_FragmentEdges(const GPUGraphStorage* g, int32_t dev_id);
+int32_t GPUGraphStorage_FragmentChunkCount(const GPUGraphStorage* g, int32_t dev_id, int32_t which);
+int64_t GPUGraphStorage_FragmentChunkSpan(const GPUGraphStorage* g, int32_t which);
+void* GPUGraphStorage_GetFragmentChunk(const GPUGraphStorage* g, int32_t dev_id, int32_t which, int32_t chunk);
+int GPUGraphStorage_ExportFragmentChunk(GPUGraphStorage* g, int32_t dev_id, int32_t which, int32_t chunk, void* handle64);
+int GPUGraphStorage_ImportFragmentChunk(GPUGraphStorage* g, int32_t owner_dev, int32_t viewer_dev, int32_t which, int32_t chunk,
+                                        const void* handle64, int32_t rows, int64_t edges);
+/* HIP-IPC exchange of a single-chunk fragment (64-byte handles); returns 0 on success */
 int GPUGraphStorage_ExportFragment(GPUGraphStorage* g, int32_t dev_id, void* handle_indptr64, void* handle_indices64, int32_t* rows_out);
 int GPUGraphStorage_ImportFragment(GPUGraphStorage* g, int32_t owner_dev, int32_t viewer_dev, const void* handle_indptr64,
                                    const void* handle_indices64, int32_t rows);

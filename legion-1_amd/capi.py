@@ -86,6 +86,13 @@ _SIGS = {
     "GPUGraphStorage_ExportFragment": (C.c_int, [vp, i32, vp, vp, vp]),
     "GPUGraphStorage_ImportFragment": (C.c_int, [vp, i32, i32, vp, vp, i32]),
     "GPUGraphStorage_GetFragmentMatrix": (vp, [vp, i32, i32]),
+    "GPUGraphStorage_FragmentRows": (i32, [vp, i32]),
+    "GPUGraphStorage_FragmentEdges": (C.c_int64, [vp, i32]),
+    "GPUGraphStorage_FragmentChunkCount": (i32, [vp, i32, i32]),
+    "GPUGraphStorage_FragmentChunkSpan": (C.c_int64, [vp, i32]),
+    "GPUGraphStorage_GetFragmentChunk": (vp, [vp, i32, i32, i32]),
+    "GPUGraphStorage_ExportFragmentChunk": (C.c_int, [vp, i32, i32, i32, vp]),
+    "GPUGraphStorage_ImportFragmentChunk": (C.c_int, [vp, i32, i32, i32, i32, vp, i32, C.c_int64]),
     "NewGPUMemoryNodeStorage": (vp, []),
     "GPUNodeStorage_Build": (None, [vp, vp]),
     "GPUNodeStorage_Delete": (None, [vp]),
@@ -437,10 +444,9 @@ class Engine:
 
     # ---- one process per GPU: exchange the clique's cache shards / CSR fragments over HIP IPC -----------------
     def export_shards(self, dev):
-        """(feature_handle, indptr_handle, indices_handle, fragment_rows) of a LOCAL clique member."""
+        """(feature_chunk_handles, indptr_chunk_handles, indices_chunk_handles, (fragment_rows, fragment_edges)) of a
+        LOCAL clique member; every handle is a 64-byte HIP IPC handle of one chunk allocation."""
         L = self.L
-        ih, xh = (C.create_string_buffer(64) for _ in range(2))
-        rows = C.c_int32(0)
         fh = []
         if L.GPUCache_Float_Feature_Cache(self.cache, dev):
             for q in range(L.GPUCache_ShardChunkCount(self.cache, dev)):
@@ -448,22 +454,31 @@ class Engine:
                 if L.GPUCache_ExportFeatureShardChunk(self.cache, dev, q, b) != 0:
                     break
                 fh.append(b.raw)
-        have_f = len(fh) > 0
-        have_t = L.GPUGraphStorage_GetFragmentIndex(self.graph, dev, dev) and \
-            L.GPUGraphStorage_ExportFragment(self.graph, dev, ih, xh, C.byref(rows)) == 0
+        th = [[], []]
+        rows, edges = L.GPUGraphStorage_FragmentRows(self.graph, dev), L.GPUGraphStorage_FragmentEdges(self.graph, dev)
+        if rows > 0:
+            for which in (0, 1):
+                for q in range(L.GPUGraphStorage_FragmentChunkCount(self.graph, dev, which)):
+                    b = C.create_string_buffer(64)
+                    if L.GPUGraphStorage_ExportFragmentChunk(self.graph, dev, which, q, b) != 0:
+                        break
+                    th[which].append(b.raw)
         check()
-        return (fh if have_f else None, ih.raw if have_t else None, xh.raw if have_t else None, rows.value)
+        have_t = rows > 0 and th[0] and th[1]
+        return (fh if fh else None, th[0] if have_t else None, th[1] if have_t else None, (rows, edges))
 
     def import_shards(self, owner_dev, handles, viewer_devs=None):
         """Open a REMOTE member's shards so that the local members read them in-kernel (xGMI peer loads)."""
         L = self.L
-        fh, ih, xh, rows = handles
+        fh, ih, xh, (rows, edges) = handles
         if fh is not None:
             for q, h in enumerate(fh):
                 L.GPUCache_ImportFeatureShardChunk(self.cache, owner_dev, q, h)
         if ih is not None:
             for v in (self.local_devs if viewer_devs is None else viewer_devs):
-                L.GPUGraphStorage_ImportFragment(self.graph, owner_dev, v, ih, xh, rows)
+                for which, hs in ((0, ih), (1, xh)):
+                    for q, h in enumerate(hs):
+                        L.GPUGraphStorage_ImportFragmentChunk(self.graph, owner_dev, v, which, q, h, rows, edges)
         check()
 
     def close(self):

@@ -49,9 +49,13 @@ struct FastDiv {
 };
 
 // ---- kernel launch API (kernels.hip) -------------------------------------------------------------
-struct CsrTables {                 // GPU_Memory_Graph_Storage.cu:45-133: P+1 slots, [P] = whole CSR
-    const int64_t* indptr[kMaxParts + 1];
-    const int32_t* indices[kMaxParts + 1];
+struct CsrTables {                 // GPU_Memory_Graph_Storage.cu:45-133: the whole CSR + the clique's fragments
+    const int64_t* indptr;         // whole CSR (the reference's slot [P]): HBM replica or pinned host table
+    const int32_t* indices;
+    // fragments are lists of chunk allocations (see GPUGraphStorage): device-side pointer tables, part-major
+    const int64_t* const* frag_indptr;  // [P * ip_nch]; chunk q of part p holds indptr entries [q<<row_shift, ((q+1)<<row_shift)]
+    const int32_t* const* frag_indices; // [P * ix_nch]; chunk q holds the rows whose first edge lies in [q<<edge_shift, (q+1)<<edge_shift)
+    int32_t ip_nch, ix_nch, row_shift, edge_shift;
     int32_t partition_count;
     const int8_t* topo_owner;      // int8[V]  owner logical GPU or -1 (edge_index_map), may be null
     const int32_t* topo_row;       // int32[V] row in the owner's fragment (edge_offset_map)
@@ -122,7 +126,9 @@ void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t
                            const int64_t* indptr, int64_t* count_out);
 void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
                          const int64_t* indptr, const int32_t* indices, const int64_t* frag_indptr,
-                         int32_t* frag_indices);
+                         int32_t* const* frag_chunks, int32_t edge_shift);
+// ends[q] = end offset of the last row that starts before (q+1) << edge_shift   (q < nch - 1)
+void launch_chunk_ends(hipStream_t s, const int64_t* frag_indptr, int32_t capacity, int32_t edge_shift, int32_t nch, int64_t* ends);
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr);
 void sort_by_hotness_desc(hipStream_t s, unsigned long long* keys, int32_t* ids, int32_t n);
 void inclusive_scan_u64(hipStream_t s, const uint64_t* in, uint64_t* out, int32_t n);
@@ -173,14 +179,26 @@ struct GPUGraphStorage {
     std::vector<int32_t*> replica_indices;
     int32_t csr_location = LEGION_LOC_HOST_PINNED;
     bool owns_csr = false;
-    // fragments per logical GPU (device memory on that GPU's physical device)
-    std::vector<int64_t*> frag_indptr;
-    std::vector<int32_t*> frag_indices;
-    std::vector<int32_t> frag_rows;
-    std::vector<bool> frag_imported;         // fragment opened from another process' IPC handle
-    // which fragments logical GPU d may read (its clique): table[d][p]
-    std::vector<std::vector<int64_t*>> view_indptr;
-    std::vector<std::vector<int32_t*>> view_indices;
+    // CSR fragment of one logical GPU (device memory on that GPU's physical device).  Both arrays are lists of
+    // chunk allocations (<= $LEGION_SHARD_CHUNK_BYTES, default 1 GiB, like the feature shards) so that every piece
+    // can be opened over HIP IPC.  indptr chunk q: entries [q<<row_shift, min(rows, (q+1)<<row_shift)] (one entry of
+    // overlap, so ip[r] and ip[r+1] come from the same chunk).  indices chunk q: every row whose first edge offset o
+    // satisfies o >> edge_shift == q, whole, at element o & mask (the chunk is as long as its last row needs).
+    struct Fragment {
+        int32_t rows = 0;
+        int64_t edges = 0;
+        std::vector<int64_t*> ip;
+        std::vector<int32_t*> ix;
+        bool imported = false;               // opened from another process' IPC handles
+        bool complete = false;               // every chunk present (built locally, or all chunks imported)
+    };
+    std::vector<Fragment> frag;
+    int32_t row_shift = 27, edge_shift = 28;
+    // which fragments logical GPU d may read (its clique): view[d][p]
+    std::vector<std::vector<bool>> view;
+    // device-side chunk-pointer tables per local viewer (P*ip_nch indptr pointers, then P*ix_nch indices pointers)
+    std::vector<void**> d_frag_tab;
+    int32_t ip_nch = 1, ix_nch = 1;
 };
 
 struct GPUNodeStorage {

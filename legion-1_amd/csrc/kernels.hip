@@ -167,7 +167,6 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
     const int32_t total = N * f; // int32 like the reference (Kernels.cu:375)
     const int32_t* __restrict__ input = (a.op_id == 2) ? a.sampled_ids : a.agg_src_ids + a.ec[2];
     const int32_t n_tiles = (total + kTile - 1) / kTile;
-    const int P = a.csr.partition_count;
     const int tid = threadIdx.x;
 
     if ((int32_t)blockIdx.x >= n_tiles) return;
@@ -193,20 +192,26 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
             const int32_t* rowp = nullptr;
             int32_t deg = -1;
             if (src >= 0) {
-                int32_t row = src;
-                const int64_t* ip = a.csr.indptr[P];
-                const int32_t* ix = a.csr.indices[P];
+                const int64_t* ip = a.csr.indptr + src;
+                const int32_t* ix = a.csr.indices;
+                int64_t start;
                 if (PARTITIONED && !PRESC) {
                     const int8_t owner = a.csr.topo_owner[src]; // FindTopo fused (GPUCache.cu:434-443)
-                    if (owner >= 0) {
-                        row = a.csr.topo_row[src];
-                        for (int p = 0; p < P; p++) // uniform index into the kernel-argument tables
-                            if (owner == p) { ip = a.csr.indptr[p]; ix = a.csr.indices[p]; }
+                    if (owner >= 0) {   // cached row: chunk tables of the owner's fragment (local HBM or xGMI peer)
+                        const int32_t row = a.csr.topo_row[src];
+                        ip = a.csr.frag_indptr[owner * a.csr.ip_nch + (row >> a.csr.row_shift)] + (row & ((1 << a.csr.row_shift) - 1));
+                        start = ip[0];
+                        ix = a.csr.frag_indices[owner * a.csr.ix_nch + (int32_t)(start >> a.csr.edge_shift)];
+                        rowp = ix + (start & ((1ll << a.csr.edge_shift) - 1));
+                    } else {
+                        start = ip[0];
+                        rowp = ix + start;
                     }
+                } else {
+                    start = ip[0];
+                    rowp = ix + start;
                 }
-                const int64_t start = ip[row];
-                deg = (int32_t)(ip[row + 1] - start); // int32 truncation as in Kernels.cu:393,396
-                rowp = ix + start;
+                deg = (int32_t)(ip[1] - start); // int32 truncation as in Kernels.cu:393,396
             }
             s_row[r] = rowp;
             s_deg[r] = deg;
@@ -637,7 +642,7 @@ __global__ void k_neighbor_count(const int32_t* QT, int32_t Kg, int32_t Ki, int3
 // TopoFillUp (GPU_Memory_Graph_Storage.cu:22-34); one wave per row, lanes stride the neighbours
 __global__ void k_topo_fill_up(const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
                                const int64_t* indptr, const int32_t* indices, const int64_t* frag_indptr,
-                               int32_t* frag_indices)
+                               int32_t* const* frag_chunks, int32_t edge_shift)
 {
     const int32_t wave = (threadIdx.x + blockDim.x * blockIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int32_t r = wave; r < capacity; r += nwaves) {
@@ -645,8 +650,22 @@ __global__ void k_topo_fill_up(const int32_t* QT, int32_t Kg, int32_t Ki, int32_
         if (t >= V) continue;
         const int32_t id = QT[t];
         const int64_t s = indptr[id], c = indptr[id + 1] - s, o = frag_indptr[r];
-        for (int64_t i = lane_id(); i < c; i += 64) frag_indices[o + i] = indices[s + i];
+        int32_t* __restrict__ out = frag_chunks[o >> edge_shift] + (o & ((1ll << edge_shift) - 1)); // a row never leaves its chunk
+        for (int64_t i = lane_id(); i < c; i += 64) out[i] = indices[s + i];
     }
+}
+// end offset of the last row starting before each chunk boundary: lower bound of the boundary in frag_indptr
+__global__ void k_chunk_ends(const int64_t* frag_indptr, int32_t capacity, int32_t edge_shift, int32_t nch, int64_t* ends)
+{
+    const int32_t q = threadIdx.x + blockDim.x * blockIdx.x;
+    if (q >= nch - 1) return;
+    const int64_t boundary = (int64_t)(q + 1) << edge_shift;
+    int32_t lo = 0, hi = capacity; // frag_indptr[capacity] = total >= boundary
+    while (lo < hi) {
+        const int32_t mid = lo + (hi - lo) / 2;
+        if (frag_indptr[mid] < boundary) lo = mid + 1; else hi = mid;
+    }
+    ends[q] = frag_indptr[lo];
 }
 // GetEdgeMem (GPUCache.cu:35-41)
 __global__ void k_edge_mem(const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)
@@ -857,10 +876,16 @@ void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t
 }
 void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
                          const int64_t* indptr, const int32_t* indices, const int64_t* frag_indptr,
-                         int32_t* frag_indices)
+                         int32_t* const* frag_chunks, int32_t edge_shift)
 {
     if (capacity <= 0) return;
-    k_topo_fill_up<<<grid_for((int64_t)capacity * 64, 256), 256, 0, s>>>(QT, Kg, Ki, capacity, V, indptr, indices, frag_indptr, frag_indices);
+    k_topo_fill_up<<<grid_for((int64_t)capacity * 64, 256), 256, 0, s>>>(QT, Kg, Ki, capacity, V, indptr, indices, frag_indptr, frag_chunks, edge_shift);
+    HIP_CHECK_LAST();
+}
+void launch_chunk_ends(hipStream_t s, const int64_t* frag_indptr, int32_t capacity, int32_t edge_shift, int32_t nch, int64_t* ends)
+{
+    if (nch <= 1) return;
+    k_chunk_ends<<<(nch + 63) / 64, 64, 0, s>>>(frag_indptr, capacity, edge_shift, nch, ends);
     HIP_CHECK_LAST();
 }
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)

@@ -92,11 +92,12 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     if (slots <= 0) return;
 
     CsrTables csr;
-    for (int i = 0; i <= kMaxParts; i++) { csr.indptr[i] = nullptr; csr.indices[i] = nullptr; }
     csr.partition_count = P;
-    // slot [P]: the whole CSR -- this GPU's HBM replica when there is one, else the (pinned host) table
-    csr.indptr[P] = graph->replica_indptr[dev] ? graph->replica_indptr[dev] : graph->csr_node_index_cpu;
-    csr.indices[P] = graph->replica_indices[dev] ? graph->replica_indices[dev] : graph->csr_dst_node_ids_cpu;
+    // the whole CSR -- this GPU's HBM replica when there is one, else the (pinned host) table
+    csr.indptr = graph->replica_indptr[dev] ? graph->replica_indptr[dev] : graph->csr_node_index_cpu;
+    csr.indices = graph->replica_indices[dev] ? graph->replica_indices[dev] : graph->csr_dst_node_ids_cpu;
+    csr.frag_indptr = nullptr; csr.frag_indices = nullptr;
+    csr.ip_nch = csr.ix_nch = 1; csr.row_shift = graph->row_shift; csr.edge_shift = graph->edge_shift;
     csr.topo_owner = nullptr;
     csr.topo_row = nullptr;
     SamplerBuffers b;
@@ -110,13 +111,16 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
         if (!cache || dev >= cache->device_count || !cache->ctl[dev]->edge_access_time) { LEGION_ARG_ERROR("GPU_Random_Sampling: pre-sampling needs an initialised cache controller"); return; }
         b.edge_access_time = cache->ctl[dev]->edge_access_time;
     } else if (cache && dev < cache->device_count && cache->ctl[dev]->topo_owner && cache->ctl[dev]->edge_capacity > 0) {
-        bool any = false;
-        for (int g = 0; g < P; g++) {
-            csr.indptr[g] = graph->view_indptr[dev][g];
-            csr.indices[g] = graph->view_indices[dev][g];
-            any = any || csr.indptr[g];
+        // every fragment the topology map of this GPU can name must be readable from here
+        bool all = graph->d_frag_tab[dev] != nullptr;
+        const int Kg = cache->Kg, K0 = (dev / Kg) * Kg;
+        for (int g = K0; g < K0 + Kg && all; g++) all = graph->view[dev][g] && graph->frag[g].complete;
+        if (all) {
+            csr.frag_indptr = (const int64_t* const*)graph->d_frag_tab[dev];
+            csr.frag_indices = (const int32_t* const*)(graph->d_frag_tab[dev] + (size_t)P * graph->ip_nch);
+            csr.ip_nch = graph->ip_nch; csr.ix_nch = graph->ix_nch;
+            csr.topo_owner = cache->ctl[dev]->topo_owner; csr.topo_row = cache->ctl[dev]->topo_row;
         }
-        if (any) { csr.topo_owner = cache->ctl[dev]->topo_owner; csr.topo_row = cache->ctl[dev]->topo_row; }
     }
     launch_sample_hop((hipStream_t)strm_hdl, csr, b, count, op_id, p->hops, (int32_t)slots, is_presc != 0);
     p->bound_n = (int32_t)slots;          // next hop expands every sampled edge endpoint

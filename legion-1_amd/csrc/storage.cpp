@@ -96,14 +96,62 @@ void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info)
     g->csr_dst_node_ids_cpu = adopt_table<int32_t>(info->csr_dst_node_ids, info->total_edge_num, info->csr_location, &o2);
     g->owns_csr = o1 || o2;
     if (o1) g->csr_location = LEGION_LOC_HOST_PINNED;
-    g->frag_indptr.assign(P, nullptr);
-    g->frag_indices.assign(P, nullptr);
-    g->frag_rows.assign(P, 0);
-    g->frag_imported.assign(P, false);
+    g->frag.assign(P, GPUGraphStorage::Fragment());
     g->replica_indptr.assign(P, nullptr);
     g->replica_indices.assign(P, nullptr);
-    g->view_indptr.assign(P, std::vector<int64_t*>(P, nullptr));
-    g->view_indices.assign(P, std::vector<int32_t*>(P, nullptr));
+    g->view.assign(P, std::vector<bool>(P, false));
+    g->d_frag_tab.assign(P, nullptr);
+    // chunk geometry of the fragments: powers of two that fit $LEGION_SHARD_CHUNK_BYTES (default 1 GiB)
+    const char* env_chunk = getenv("LEGION_SHARD_CHUNK_BYTES");
+    const int64_t chunk_bytes = env_chunk ? atoll(env_chunk) : (1ll << 30);
+    g->row_shift = 4; g->edge_shift = 4;
+    while (g->row_shift < 30 && (2ll << g->row_shift) * (int64_t)sizeof(int64_t) <= chunk_bytes) g->row_shift++;
+    while (g->edge_shift < 30 && (2ll << g->edge_shift) * (int64_t)sizeof(int32_t) <= chunk_bytes) g->edge_shift++;
+}
+
+static int frag_ip_chunks(const GPUGraphStorage* g, int32_t rows) { return rows > 0 ? (int)((((int64_t)rows - 1) >> g->row_shift) + 1) : 1; }
+static int frag_ix_chunks(const GPUGraphStorage* g, int64_t edges) { return edges > 0 ? (int)(((edges - 1) >> g->edge_shift) + 1) : 1; }
+
+static void free_fragment(GPUGraphStorage::Fragment& f)
+{
+    for (int64_t* p : f.ip) if (p) { if (f.imported) (void)hipIpcCloseMemHandle(p); else (void)hipFree(p); }
+    for (int32_t* p : f.ix) if (p) { if (f.imported) (void)hipIpcCloseMemHandle(p); else (void)hipFree(p); }
+    f = GPUGraphStorage::Fragment();
+}
+
+static bool fragment_complete(const GPUGraphStorage* g, int dev)
+{
+    const auto& f = g->frag[dev];
+    if (f.rows <= 0 || (int)f.ip.size() != frag_ip_chunks(g, f.rows) || (int)f.ix.size() != frag_ix_chunks(g, f.edges)) return false;
+    for (auto* p : f.ip) if (!p) return false;
+    for (auto* p : f.ix) if (!p) return false;
+    return true;
+}
+
+// (re)write the device-side chunk-pointer tables of every local viewer
+static void publish_fragment_tables(GPUGraphStorage* g)
+{
+    const int P = g->partition_count;
+    int ip_nch = 1, ix_nch = 1;
+    for (int p = 0; p < P; p++) { ip_nch = std::max(ip_nch, (int)g->frag[p].ip.size()); ix_nch = std::max(ix_nch, (int)g->frag[p].ix.size()); }
+    const bool regrow = ip_nch != g->ip_nch || ix_nch != g->ix_nch;
+    g->ip_nch = ip_nch; g->ix_nch = ix_nch;
+    std::vector<void*> h((size_t)P * (ip_nch + ix_nch) + 1); // +1: a zero-degree row at offset == edges names chunk ix_nch
+    for (int dev = 0; dev < P; dev++) {
+        if (is_remote_device(dev)) continue;
+        bool any = false;
+        std::fill(h.begin(), h.end(), nullptr);
+        for (int p = 0; p < P; p++) {
+            if (!g->view[dev][p]) continue;
+            for (size_t q = 0; q < g->frag[p].ip.size(); q++) { h[(size_t)p * ip_nch + q] = g->frag[p].ip[q]; any = true; }
+            for (size_t q = 0; q < g->frag[p].ix.size(); q++) h[(size_t)P * ip_nch + (size_t)p * ix_nch + q] = g->frag[p].ix[q];
+        }
+        DeviceGuard guard(dev);
+        if (g->d_frag_tab[dev] && (regrow || !any)) { HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(g->d_frag_tab[dev]); g->d_frag_tab[dev] = nullptr; }
+        if (!any) continue;
+        if (!g->d_frag_tab[dev]) HIP_CHECK(hipMalloc(&g->d_frag_tab[dev], h.size() * sizeof(void*)));
+        HIP_CHECK(hipMemcpy(g->d_frag_tab[dev], h.data(), h.size() * sizeof(void*), hipMemcpyHostToDevice));
+    }
 }
 
 // GraphCache (GPU_Memory_Graph_Storage.cu:98-133): fragment of clique GPU i holds rows QT[r*Kg+i]
@@ -114,12 +162,12 @@ void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int
         const int dev = Ki * Kg + i;
         if (is_remote_device(dev)) continue; // built by its own process, imported here over IPC
         DeviceGuard guard(dev);
-        if (g->frag_indptr[dev]) { (void)hipFree(g->frag_indptr[dev]); g->frag_indptr[dev] = nullptr; }
-        if (g->frag_indices[dev]) { (void)hipFree(g->frag_indices[dev]); g->frag_indices[dev] = nullptr; }
-        g->frag_rows[dev] = capacity;
+        HIP_CHECK(hipDeviceSynchronize());
+        free_fragment(g->frag[dev]);
         if (capacity <= 0) continue;
+        GPUGraphStorage::Fragment& f = g->frag[dev];
         int64_t* neighbor_count = nullptr;
-        int64_t* d_index = nullptr;
+        int64_t* d_index = nullptr; // contiguous build copy of the fragment's indptr
         HIP_CHECK(hipMalloc(&neighbor_count, (size_t)capacity * sizeof(int64_t)));
         HIP_CHECK(hipMalloc(&d_index, ((size_t)capacity + 1) * sizeof(int64_t)));
         HIP_CHECK(hipMemset(d_index, 0, sizeof(int64_t)));
@@ -127,20 +175,51 @@ void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int
         inclusive_scan_i64(nullptr, neighbor_count, d_index + 1, capacity);
         int64_t total = 0;
         HIP_CHECK(hipMemcpy(&total, d_index + capacity, sizeof(int64_t), hipMemcpyDeviceToHost));
-        int32_t* d_ids = nullptr;
-        HIP_CHECK(hipMalloc(&d_ids, (size_t)(total > 0 ? total : 1) * sizeof(int32_t)));
-        launch_topo_fill_up(nullptr, QT, Kg, i, capacity, g->node_num, g->csr_node_index_cpu, g->csr_dst_node_ids_cpu, d_index, d_ids);
-        HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipFree(neighbor_count));
-        g->frag_indptr[dev] = d_index;
-        g->frag_indices[dev] = d_ids;
+        f.rows = capacity;
+        f.edges = total;
+        // indices chunks: chunk q ends where the last row that starts before its upper boundary ends
+        const int nx = frag_ix_chunks(g, total);
+        std::vector<int64_t> ends(nx, total);
+        if (nx > 1) {
+            int64_t* d_ends = nullptr;
+            HIP_CHECK(hipMalloc(&d_ends, (size_t)nx * sizeof(int64_t)));
+            launch_chunk_ends(nullptr, d_index, capacity, g->edge_shift, nx, d_ends);
+            HIP_CHECK(hipMemcpy(ends.data(), d_ends, (size_t)(nx - 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+            HIP_CHECK(hipFree(d_ends));
+        }
+        f.ix.assign(nx, nullptr);
+        for (int q = 0; q < nx; q++) {
+            const int64_t elems = ends[q] - ((int64_t)q << g->edge_shift); // <= 0: no row starts in this chunk
+            HIP_CHECK(hipMalloc(&f.ix[q], (size_t)(elems > 0 ? elems : 1) * sizeof(int32_t)));
+        }
+        int32_t** d_chunks = nullptr;
+        HIP_CHECK(hipMalloc(&d_chunks, ((size_t)nx + 1) * sizeof(int32_t*))); // +1: see publish_fragment_tables
+        HIP_CHECK(hipMemcpy(d_chunks, f.ix.data(), (size_t)nx * sizeof(int32_t*), hipMemcpyHostToDevice));
+        launch_topo_fill_up(nullptr, QT, Kg, i, capacity, g->node_num, g->csr_node_index_cpu, g->csr_dst_node_ids_cpu, d_index, d_chunks, g->edge_shift);
+        // indptr chunks (one entry of overlap); a single chunk adopts the build copy
+        const int np = frag_ip_chunks(g, capacity);
+        if (np == 1) {
+            f.ip.assign(1, d_index);
+            d_index = nullptr;
+        } else {
+            f.ip.assign(np, nullptr);
+            const int64_t rpc = 1ll << g->row_shift;
+            for (int q = 0; q < np; q++) {
+                const int64_t r0 = q * rpc, n = std::min<int64_t>(rpc, capacity - r0) + 1;
+                HIP_CHECK(hipMalloc(&f.ip[q], (size_t)n * sizeof(int64_t)));
+                HIP_CHECK(hipMemcpy(f.ip[q], d_index + r0, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice));
+            }
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+        HIP_CHECK(hipFree(d_chunks));
+        if (d_index) HIP_CHECK(hipFree(d_index));
+        f.complete = true;
     }
     // every clique member sees every clique fragment (pointer tables copied D2D in the reference, :128-131)
     for (int i = 0; i < Kg; i++)
-        for (int j = 0; j < Kg; j++) {
-            g->view_indptr[Ki * Kg + i][Ki * Kg + j] = g->frag_indptr[Ki * Kg + j];
-            g->view_indices[Ki * Kg + i][Ki * Kg + j] = g->frag_indices[Ki * Kg + j];
-        }
+        for (int j = 0; j < Kg; j++) g->view[Ki * Kg + i][Ki * Kg + j] = true;
+    publish_fragment_tables(g);
 }
 
 int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g)
@@ -156,17 +235,9 @@ void GPUGraphStorage_Finalize(GPUGraphStorage* g)
     if (!g) return;
     free_replicas(g->replica_indptr);
     free_replicas(g->replica_indices);
-    for (size_t i = 0; i < g->frag_indptr.size(); i++) {
-        if (g->frag_imported[i]) {
-            if (g->frag_indptr[i]) (void)hipIpcCloseMemHandle(g->frag_indptr[i]);
-            if (g->frag_indices[i]) (void)hipIpcCloseMemHandle(g->frag_indices[i]);
-            g->frag_imported[i] = false;
-        } else {
-            if (g->frag_indptr[i]) (void)hipFree(g->frag_indptr[i]);
-            if (g->frag_indices[i]) (void)hipFree(g->frag_indices[i]);
-        }
-        g->frag_indptr[i] = nullptr;
-        g->frag_indices[i] = nullptr;
+    for (size_t i = 0; i < g->frag.size(); i++) {
+        if (!is_remote_device((int)i) || g->frag[i].imported) { DeviceGuard guard((int)i); free_fragment(g->frag[i]); }
+        if (g->d_frag_tab[i]) { DeviceGuard guard((int)i); (void)hipFree(g->d_frag_tab[i]); g->d_frag_tab[i] = nullptr; }
     }
     if (g->owns_csr) {
         host_free_space(g->csr_node_index_cpu);
@@ -177,46 +248,84 @@ void GPUGraphStorage_Finalize(GPUGraphStorage* g)
 int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g) { return g->partition_count; }
 int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g) { return g->csr_node_index_cpu; }
 int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g) { return g->csr_dst_node_ids_cpu; }
-int64_t* GPUGraphStorage_GetFragmentIndex(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id)
+static bool frag_args_ok(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id)
 {
-    if (dev_id < 0 || dev_id >= g->partition_count || part_id < 0 || part_id >= g->partition_count) return nullptr;
-    return g->view_indptr[dev_id][part_id];
+    return g && dev_id >= 0 && dev_id < g->partition_count && part_id >= 0 && part_id < g->partition_count;
+}
+int64_t* GPUGraphStorage_GetFragmentIndex(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id)
+{   // first chunk (the whole indptr when the fragment has one chunk)
+    if (!frag_args_ok(g, dev_id, part_id) || !g->view[dev_id][part_id] || g->frag[part_id].ip.empty()) return nullptr;
+    return g->frag[part_id].ip[0];
 }
 int32_t* GPUGraphStorage_GetFragmentMatrix(const GPUGraphStorage* g, int32_t dev_id, int32_t part_id)
 {
-    if (dev_id < 0 || dev_id >= g->partition_count || part_id < 0 || part_id >= g->partition_count) return nullptr;
-    return g->view_indices[dev_id][part_id];
+    if (!frag_args_ok(g, dev_id, part_id) || !g->view[dev_id][part_id] || g->frag[part_id].ix.empty()) return nullptr;
+    return g->frag[part_id].ix[0];
+}
+int32_t GPUGraphStorage_FragmentRows(const GPUGraphStorage* g, int32_t dev_id) { return frag_args_ok(g, dev_id, 0) ? g->frag[dev_id].rows : 0; }
+int64_t GPUGraphStorage_FragmentEdges(const GPUGraphStorage* g, int32_t dev_id) { return frag_args_ok(g, dev_id, 0) ? g->frag[dev_id].edges : 0; }
+int32_t GPUGraphStorage_FragmentChunkCount(const GPUGraphStorage* g, int32_t dev_id, int32_t which)
+{
+    if (!frag_args_ok(g, dev_id, 0)) return 0;
+    return which == 0 ? (int32_t)g->frag[dev_id].ip.size() : (int32_t)g->frag[dev_id].ix.size();
+}
+int64_t GPUGraphStorage_FragmentChunkSpan(const GPUGraphStorage* g, int32_t which)
+{
+    return g ? (1ll << (which == 0 ? g->row_shift : g->edge_shift)) : 0;
+}
+void* GPUGraphStorage_GetFragmentChunk(const GPUGraphStorage* g, int32_t dev_id, int32_t which, int32_t chunk)
+{
+    if (!frag_args_ok(g, dev_id, 0) || chunk < 0 || chunk >= GPUGraphStorage_FragmentChunkCount(g, dev_id, which)) return nullptr;
+    return which == 0 ? (void*)g->frag[dev_id].ip[chunk] : (void*)g->frag[dev_id].ix[chunk];
+}
+int GPUGraphStorage_ExportFragmentChunk(GPUGraphStorage* g, int32_t dev_id, int32_t which, int32_t chunk, void* handle64)
+{
+    void* p = GPUGraphStorage_GetFragmentChunk(g, dev_id, which, chunk);
+    if (!p || !handle64 || g->frag[dev_id].imported) { LEGION_ARG_ERROR("ExportFragmentChunk: no such local chunk"); return -1; }
+    DeviceGuard guard(dev_id);
+    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, p));
+    return error_pending() ? -1 : 0;
+}
+int GPUGraphStorage_ImportFragmentChunk(GPUGraphStorage* g, int32_t owner_dev, int32_t viewer_dev, int32_t which, int32_t chunk,
+                                        const void* handle64, int32_t rows, int64_t edges)
+{
+    if (!frag_args_ok(g, owner_dev, viewer_dev) || !handle64 || !is_remote_device(owner_dev) || rows <= 0 || edges < 0) { LEGION_ARG_ERROR("ImportFragmentChunk: owner must be a remote member"); return -1; }
+    GPUGraphStorage::Fragment& f = g->frag[owner_dev];
+    if (!f.imported) {
+        f.rows = rows; f.edges = edges; f.imported = true;
+        f.ip.assign(frag_ip_chunks(g, rows), nullptr);
+        f.ix.assign(frag_ix_chunks(g, edges), nullptr);
+    }
+    if (f.rows != rows || f.edges != edges) { LEGION_ARG_ERROR("ImportFragmentChunk: rows/edges differ from the first chunk's"); return -1; }
+    const int n = which == 0 ? (int)f.ip.size() : (int)f.ix.size();
+    if (chunk < 0 || chunk >= n) { LEGION_ARG_ERROR("ImportFragmentChunk: chunk out of range"); return -1; }
+    void*& slot = which == 0 ? (void*&)f.ip[chunk] : (void*&)f.ix[chunk];
+    if (!slot) {
+        DeviceGuard guard(viewer_dev);
+        hipIpcMemHandle_t h;
+        memcpy(&h, handle64, sizeof(h));
+        void* p = nullptr;
+        HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        if (!p) return -1;
+        slot = p;
+    }
+    g->view[viewer_dev][owner_dev] = true;
+    f.complete = fragment_complete(g, owner_dev);
+    if (f.complete) publish_fragment_tables(g);
+    return 0;
 }
 int GPUGraphStorage_ExportFragment(GPUGraphStorage* g, int32_t dev_id, void* handle_indptr64, void* handle_indices64, int32_t* rows_out)
-{
-    if (!g || dev_id < 0 || dev_id >= g->partition_count || !g->frag_indptr[dev_id] || g->frag_imported[dev_id]) { LEGION_ARG_ERROR("ExportFragment: no local fragment"); return -1; }
-    DeviceGuard guard(dev_id);
-    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle_indptr64, g->frag_indptr[dev_id]));
-    HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle_indices64, g->frag_indices[dev_id]));
-    if (rows_out) *rows_out = g->frag_rows[dev_id];
-    return error_pending() ? -1 : 0;
+{   // single-chunk fragments only; chunked fragments use the *Chunk calls
+    if (GPUGraphStorage_FragmentChunkCount(g, dev_id, 0) != 1 || GPUGraphStorage_FragmentChunkCount(g, dev_id, 1) != 1) { LEGION_ARG_ERROR("ExportFragment: fragment has several chunks, use ExportFragmentChunk"); return -1; }
+    if (rows_out) *rows_out = g->frag[dev_id].rows;
+    if (GPUGraphStorage_ExportFragmentChunk(g, dev_id, 0, 0, handle_indptr64) != 0) return -1;
+    return GPUGraphStorage_ExportFragmentChunk(g, dev_id, 1, 0, handle_indices64);
 }
 int GPUGraphStorage_ImportFragment(GPUGraphStorage* g, int32_t owner_dev, int32_t viewer_dev, const void* handle_indptr64,
                                    const void* handle_indices64, int32_t rows)
-{
-    if (!g || owner_dev < 0 || owner_dev >= g->partition_count || viewer_dev < 0 || viewer_dev >= g->partition_count || !is_remote_device(owner_dev)) { LEGION_ARG_ERROR("ImportFragment: owner must be a remote member"); return -1; }
-    DeviceGuard guard(viewer_dev);
-    if (!g->frag_indptr[owner_dev]) {
-        hipIpcMemHandle_t h1, h2;
-        memcpy(&h1, handle_indptr64, sizeof(h1));
-        memcpy(&h2, handle_indices64, sizeof(h2));
-        void *p1 = nullptr, *p2 = nullptr;
-        HIP_CHECK(hipIpcOpenMemHandle(&p1, h1, hipIpcMemLazyEnablePeerAccess));
-        HIP_CHECK(hipIpcOpenMemHandle(&p2, h2, hipIpcMemLazyEnablePeerAccess));
-        if (!p1 || !p2) return -1;
-        g->frag_indptr[owner_dev] = (int64_t*)p1;
-        g->frag_indices[owner_dev] = (int32_t*)p2;
-        g->frag_rows[owner_dev] = rows;
-        g->frag_imported[owner_dev] = true;
-    }
-    g->view_indptr[viewer_dev][owner_dev] = g->frag_indptr[owner_dev];
-    g->view_indices[viewer_dev][owner_dev] = g->frag_indices[owner_dev];
-    return 0;
+{   // single-chunk form: the edge count is not known here, any value inside the first chunk selects one chunk
+    if (GPUGraphStorage_ImportFragmentChunk(g, owner_dev, viewer_dev, 0, 0, handle_indptr64, rows, 1) != 0) return -1;
+    return GPUGraphStorage_ImportFragmentChunk(g, owner_dev, viewer_dev, 1, 0, handle_indices64, rows, 1);
 }
 void GPUGraphStorage_Delete(GPUGraphStorage* g)
 {

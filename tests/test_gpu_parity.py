@@ -269,10 +269,31 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
                                                     min(rpc, cm["node_capacity"] - q * rpc) * F).reshape(-1, F) for q in range(nch)])
             n_valid = len(range(j, min(V, cm["node_capacity"] * Kg), Kg))
             assert np.array_equal(cache_rows[:n_valid], orcs[m].caches[j][:n_valid])
-            fi = K.read_dev(L.GPUGraphStorage_GetFragmentIndex(eng.graph, m, m), np.int64, cm["edge_capacity"] + 1)
+            # CSR fragment, reassembled from its chunk allocations (one chunk unless chunk_bytes is small)
+            ecap = cm["edge_capacity"]
+            assert L.GPUGraphStorage_FragmentRows(eng.graph, m) == ecap
+            rspan, espan = (L.GPUGraphStorage_FragmentChunkSpan(eng.graph, w) for w in (0, 1))
+            nip, nix = (L.GPUGraphStorage_FragmentChunkCount(eng.graph, m, w) for w in (0, 1))
+            assert nip == (ecap - 1) // rspan + 1
+            fi = np.empty(ecap + 1, np.int64)
+            for q in range(nip):
+                n = min(rspan, ecap - q * rspan) + 1
+                fi[q * rspan:q * rspan + n] = K.read_dev(L.GPUGraphStorage_GetFragmentChunk(eng.graph, m, 0, q), np.int64, n)
             assert np.array_equal(fi, orcs[m].frag_indptr[m])
-            fx = K.read_dev(L.GPUGraphStorage_GetFragmentMatrix(eng.graph, m, m), np.int32, int(fi[-1]))
-            assert np.array_equal(fx, orcs[m].frag_indices[m][:int(fi[-1])])
+            total = int(fi[-1])
+            assert L.GPUGraphStorage_FragmentEdges(eng.graph, m) == total and nix == max(1, (total - 1) // espan + 1)
+            assert (nip == nix == 1) if chunk_bytes is None else (nix > 1)
+            fx = np.full(total, -7, np.int32)
+            for q in range(nix):
+                first = np.flatnonzero((fi[:-1] >> int(np.log2(espan))) == q)      # rows that start in chunk q
+                if len(first) == 0:
+                    continue
+                lo, end = int(fi[first[0]]), int(fi[first[-1] + 1])   # [q*espan, lo) belongs to a row of the previous chunk
+                fx[lo:end] = K.read_dev(L.GPUGraphStorage_GetFragmentChunk(eng.graph, m, 1, q), np.int32, end - q * espan)[lo - q * espan:]
+            assert np.array_equal(fx, orcs[m].frag_indices[m][:total])
+            if nip == 1 and nix == 1:
+                assert L.GPUGraphStorage_GetFragmentIndex(eng.graph, m, m) == L.GPUGraphStorage_GetFragmentChunk(eng.graph, m, 0, 0)
+                assert L.GPUGraphStorage_GetFragmentMatrix(eng.graph, m, m) == L.GPUGraphStorage_GetFragmentChunk(eng.graph, m, 1, 0)
             for b in (d_in, d_nc, d_out, d_pi, d_po):
                 b.free()
     # steady state through the unified cache (local + peer shards + backing-table misses)

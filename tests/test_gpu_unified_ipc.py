@@ -70,11 +70,15 @@ def _worker(rank, world, port, q):
         # exchange the shards over HIP IPC
         mine = eng.export_shards(rank)
         assert mine[0] is not None and len(mine[0]) == L.GPUCache_ShardChunkCount(eng.cache, rank) > 1 and mine[1] is not None
+        assert len(mine[2]) == L.GPUGraphStorage_FragmentChunkCount(eng.graph, rank, 1) > 1      # CSR fragment in several chunks too
         everyone = D.allgather_object(mine, world)
         for g in range(world):
             if g != rank:
                 eng.import_shards(g, everyone[g])
         assert L.GPUCache_Float_Feature_Cache(eng.cache, 1 - rank)
+        assert L.GPUGraphStorage_GetFragmentIndex(eng.graph, rank, 1 - rank)                       # peer fragment visible from here
+        assert L.GPUGraphStorage_FragmentChunkCount(eng.graph, 1 - rank, 1) == len(everyone[1 - rank][2])
+        assert L.GPUGraphStorage_FragmentEdges(eng.graph, 1 - rank) == everyone[1 - rank][3][1]
         # steady state through the unified cache: own shard, peer shard (IPC) and backing-table misses
         me = orcs[rank]
         me.set_feature_cache(QF, cap, world)

@@ -152,6 +152,7 @@ struct SampleArgs {
     FastDiv fdiv;              // / count
     int32_t count;
     int32_t op_id;
+    int32_t window;            // lanes to look back for a repeated draw of the same row: min(count - 1, 8)
 };
 
 template <bool PRESC, bool PARTITIONED>
@@ -223,34 +224,46 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile_start + tid + kBlock * s;
-            int32_t dst = -1, known = -1;
+            int32_t dst = -1, known = -1, j = 0, r = 0;
             if (idx < tile_end) {
                 const uint32_t i = fdiv((uint32_t)idx, a.fdiv);
-                const int32_t j = idx - (int32_t)i * f;
-                const int32_t r = (int32_t)i - i0;
+                j = idx - (int32_t)i * f;
+                r = (int32_t)i - i0;
                 const int32_t deg = s_deg[r];
                 if (j < deg) { // deg == -1 for padded (-1) sources; Kernels.cu:385,399
-                    const int32_t k = sample_index(x[s], deg);
-                    dst = s_row[r][k];
-                    if (dst >= 0) {
-                        if (PRESC) atomicAdd(a.edge_access_time + s_src[r], 1ull); // Kernels.cu:525
-                        // claim: lowest idx wins.  A stale (larger) read only costs a redundant atomic.
-                        // Entries of older batches have a larger epoch field, i.e. compare greater: unseen.
-                        const unsigned long long mine = ((unsigned long long)a.epoch << 32) | kProvisional | (uint32_t)idx;
-                        const unsigned long long cur = a.pos_map[dst];
-                        if (cur > mine) atomicMin(a.pos_map + dst, mine);
-                        // final positions are only written by earlier launches: if we see one it is exact,
-                        // and k_mark need not probe the table for this slot again
-                        if (cur < (((unsigned long long)a.epoch << 32) | kProvisional)) known = (int32_t)(uint32_t)cur;
-                        // a smaller claim of this hop is already in the table: this slot has lost for good
-                        // (claims only decrease).  Point at that slot; if it loses later too, its own aux
-                        // points further, and k_resolve follows the chain to the winner.
-                        else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & 0x7FFFFFFFu);
-                        cnt++;
-                    } else {
-                        dst = -1;
-                    }
+                    dst = s_row[r][sample_index(x[s], deg)];
+                    if (dst < 0) dst = -1;
                 }
+            }
+            // Draws are with replacement, so the f slots of a row repeat neighbours (f = 5 of ~14: every 7th
+            // slot).  The slots of a row sit in adjacent lanes: a lane that finds its neighbour in an earlier
+            // lane of the same row has lost to it for good -- no table probe, no claim, and k_mark skips it too.
+            int32_t dup = 0;
+            for (int d = 1; d <= a.window; d++) { // uniform trip count, executed by the whole wave
+                const int32_t o = __shfl_up(dst, d);
+                if (d <= j && d <= lane_id() && o == dst) dup = d; // keeps the earliest match: short chains
+            }
+            if (dst >= 0) {
+                if (PRESC) atomicAdd(a.edge_access_time + s_src[r], 1ull); // Kernels.cu:525
+                if (dup) {
+                    known = -2 - (idx - dup);
+                } else {
+                    // claim: lowest idx wins.  A stale (larger) read only costs a redundant atomic.
+                    // Entries of older batches have a larger epoch field, i.e. compare greater: unseen.
+                    const unsigned long long mine = ((unsigned long long)a.epoch << 32) | kProvisional | (uint32_t)idx;
+                    const unsigned long long cur = a.pos_map[dst];
+                    if (cur > mine) atomicMin(a.pos_map + dst, mine);
+                    // final positions are only written by earlier launches: if we see one it is exact,
+                    // and k_mark need not probe the table for this slot again
+                    if (cur < (((unsigned long long)a.epoch << 32) | kProvisional)) known = (int32_t)(uint32_t)cur;
+                    // a smaller claim of this hop is already in the table: this slot has lost for good
+                    // (claims only decrease).  Point at that slot; if it loses later too, its own aux
+                    // points further, and k_resolve follows the chain to the winner.
+                    else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & 0x7FFFFFFFu);
+                }
+                cnt++;
+            }
+            if (idx < tile_end) {
                 a.cand[idx] = dst;
                 a.aux[idx] = known;
             }
@@ -753,6 +766,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     a.a_step = powmod31(kA, (uint64_t)kTile * (uint64_t)grid);
     a.fdiv = FastDiv((uint32_t)count);
     a.count = count; a.op_id = op_id;
+    a.window = std::min(count - 1, 8);
     const bool part = csr.topo_owner != nullptr;
     if (is_presc) k_sample<true, false><<<grid, kBlock, 0, s>>>(a);
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);

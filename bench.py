@@ -290,6 +290,25 @@ def main():
                "value": round(job_edges / alt_max, 1), "unit": "edges/s",
                "pipeline_frac": round(job_bytes / alt_max / 1e9 / (HBM_PEAK_GBPS * world), 4)}
 
+    # the serial schedule again, recorded once as a hipGraph and replayed with one launch per batch (same K batches)
+    graph_leg = None
+    if not per_level and not intra:
+        L.GPUMemoryPool_SetCurrentPipe(pool, 0)
+        hgraph = eng.capture_batch(me, pipe=0, per_level=False, plan=True, stream=stream)
+        eng.run_graph(hgraph, W % steps_avail, sync=True)
+        if world > 1:
+            torch.distributed.barrier()
+        t_g = time.perf_counter()
+        for i in range(K_steps):
+            eng.run_graph(hgraph, (W + i) % steps_avail, sync=False)
+        drain()
+        g_elapsed = time.perf_counter() - t_g
+        if world > 1:
+            torch.distributed.barrier()
+        g_max, _ = D.aggregate(g_elapsed, [0.0], world, device=dev)
+        graph_leg = {"pipeline": "serial, one hipGraph launch per batch", "ms_per_step": round(g_max / K_steps * 1e3, 4),
+                     "value": round(job_edges / g_max, 1), "unit": "edges/s"}
+
     # dominant kernel (k_gather: it moves ~94 % of the batch's algorithmic bytes), HIP events on its stream
     roofline = None
     if not per_level:
@@ -368,6 +387,7 @@ def main():
             "unique_nodes_per_batch": round(job_nodes / (K_steps * world), 1),
             "graph_gen_s": round(gen_s, 2),
             "alt_schedule": alt,
+            "graph_replay": graph_leg,
             "cache": {"mode": args.cache, **(cache_info or {}), **(xgmi or {})},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -45,6 +45,7 @@ typedef struct IPCEnv IPCEnv;                   /* CUDA_IPC_Service.h:6-33 */
 typedef struct Operator Operator;               /* Operator.h:18-21 */
 typedef struct Runner Runner;                   /* Server.h:157-165 */
 typedef struct Server Server;                   /* Server.h:148-155 */
+typedef struct LegionBatchGraph LegionBatchGraph; /* one recorded mini-batch (hipGraph); no reference counterpart */
 
 /* ---- library control --------------------------------------------------------------------- */
 #define LEGION_ERR_EXIT 0   /* reference behaviour */
@@ -212,6 +213,17 @@ uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p);
 /* batches started on this pool (the table epoch is 0xFFFFFFFF - serial); settable to exercise the wrap-around */
 uint32_t GPUMemoryPool_GetBatchSerial(const GPUMemoryPool* p);
 void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial);
+/* Batch graphs: record the launcher calls of ONE mini-batch (GPURunner::RunOnce's operator loop, Server.cu:309-323)
+ * as a hipGraph and replay it with one launch per batch.  Between Begin and End call the usual launchers
+ * (batch_generator_kernel .. get_feature_kernel .. make_update_plan) on `stream` (not the null stream; other
+ * streams may join through events and must be joined back before End); batch_generator_kernel's `counter` is
+ * ignored while recording -- the batch cursor and the table epoch are device-resident and stepped by the graph
+ * itself.  The graph is bound to the pool, the pipe and the mode it was recorded with.  Launch(graph, stream,
+ * counter) runs the batch that batch_generator_kernel(.., counter, ..) would; returns 0 on success. */
+int GPUMemoryPool_BeginBatchCapture(GPUMemoryPool* p, void* stream);
+LegionBatchGraph* GPUMemoryPool_EndBatchCapture(GPUMemoryPool* p, void* stream);
+int LegionBatchGraph_Launch(LegionBatchGraph* g, void* stream, int32_t counter);
+void LegionBatchGraph_Delete(LegionBatchGraph* g);
 void GPUMemoryPool_Finalize(GPUMemoryPool* p);
 void GPUMemoryPool_Delete(GPUMemoryPool* p);
 

@@ -86,6 +86,10 @@ _SIGS = {
     "GPUGraphStorage_ExportFragment": (C.c_int, [vp, i32, vp, vp, vp]),
     "GPUGraphStorage_ImportFragment": (C.c_int, [vp, i32, i32, vp, vp, i32]),
     "GPUGraphStorage_GetFragmentMatrix": (vp, [vp, i32, i32]),
+    "GPUMemoryPool_BeginBatchCapture": (C.c_int, [vp, vp]),
+    "GPUMemoryPool_EndBatchCapture": (vp, [vp, vp]),
+    "LegionBatchGraph_Launch": (C.c_int, [vp, vp, i32]),
+    "LegionBatchGraph_Delete": (None, [vp]),
     "GPUGraphStorage_FragmentRows": (i32, [vp, i32]),
     "GPUGraphStorage_FragmentEdges": (C.c_int64, [vp, i32]),
     "GPUGraphStorage_FragmentChunkCount": (i32, [vp, i32, i32]),
@@ -373,6 +377,7 @@ class Engine:
             self.pools[g] = pool
             self.out[g] = pipes
         self.streams = [None] * self.G
+        self._graphs = []
         check()
 
     # ---- feature buffers ------------------------------------------------------------------------------
@@ -412,6 +417,38 @@ class Engine:
             L.update_cache(stream, self.cache, self.noder, pool, dev, mode)
         if sync:
             L.d_stream_sync(stream)
+            check()
+
+    # ---- the same batch recorded once as a hipGraph (one launch per batch) ---------------------------------------
+    def capture_batch(self, dev=0, mode=TRAINMODE, gather=True, plan=True, pipe=0, batch_size=None, per_level=True,
+                      stream=None):
+        """Record run_batch(dev, <any counter>, mode, ...) on `stream`; returns the graph handle for run_graph()."""
+        L = self.L
+        L.SetGPUDevice(dev)
+        if stream is None:
+            if self.streams[dev] is None:
+                self.streams[dev] = L.d_stream_create()
+            stream = self.streams[dev]
+        if L.GPUMemoryPool_BeginBatchCapture(self.pools[dev], stream) != 0:
+            check()
+            raise RuntimeError("BeginBatchCapture failed")
+        self.run_batch(dev, 0, mode=mode, gather=gather, plan=plan, pipe=pipe, batch_size=batch_size, per_level=per_level,
+                       stream=stream, sync=False)
+        g = L.GPUMemoryPool_EndBatchCapture(self.pools[dev], stream)
+        check()
+        if not g:
+            raise RuntimeError("EndBatchCapture failed")
+        self._graphs.append(g)
+        return (g, stream, dev)
+
+    def run_graph(self, handle, counter, sync=True):
+        g, stream, dev = handle
+        self.L.SetGPUDevice(dev)
+        if self.L.LegionBatchGraph_Launch(g, stream, int(counter)) != 0:
+            check()
+            raise RuntimeError("LegionBatchGraph_Launch failed")
+        if sync:
+            self.L.d_stream_sync(stream)
             check()
 
     def result(self, dev=0, pipe=0, with_features=True):
@@ -483,6 +520,14 @@ class Engine:
 
     def close(self):
         L = self.L
+        for g in self._graphs:
+            L.LegionBatchGraph_Delete(g)
+        self._graphs = []
+        for d, st in enumerate(self.streams):
+            if st is not None:
+                L.SetGPUDevice(d)
+                L.d_stream_destroy(st)
+        self.streams = [None] * self.G
         for g, pool in enumerate(self.pools):
             if pool is None:
                 continue

@@ -61,6 +61,11 @@ struct CsrTables {                 // GPU_Memory_Graph_Storage.cu:45-133: the wh
     const int32_t* topo_row;       // int32[V] row in the owner's fragment (edge_offset_map)
 };
 
+struct BatchCtl {                  // device-resident batch cursor (see k_seed)
+    int32_t counter;               // batch index inside the seed list
+    uint32_t epoch;                // position-table epoch of the running batch
+};
+
 struct HopState {                  // written by the scan kernel, read by the write/resolve kernels
     int32_t edge_base, node_base, n_edges, n_nodes, in_off, n_in, slots, pad;
 };
@@ -73,7 +78,7 @@ struct SamplerBuffers {
     int32_t* nc;            // IPC buffer 5
     int32_t* ec;            // IPC buffer 6
     unsigned long long* pos_map; // u64[V]: (epoch << 32) | value
-    uint32_t epoch;         // 0xFFFFFFFF - batch serial: newer batches compare smaller
+    const BatchCtl* ctl;    // ctl->epoch = 0xFFFFFFFF - batch serial: newer batches compare smaller
     int32_t* cand;          // i32[max slots of a hop]
     int32_t* aux;           // i32[max slots of a hop]: known final position or -1
     int32_t* tile_edge;     // i32[max tiles]
@@ -82,9 +87,12 @@ struct SamplerBuffers {
     unsigned long long* edge_access_time; // pre-sampling only (may be null)
 };
 
-void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size, int32_t counter,
+void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t batch_size, int32_t size, int32_t counter,
                  const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
-                 uint32_t epoch, int32_t* nc, int32_t* ec);
+                 uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec);
+void launch_set_cursor(hipStream_t s, BatchCtl* ctl, int32_t counter, uint32_t epoch);
+void launch_advance(hipStream_t s, BatchCtl* ctl);
+void warm_static_tables();   // per-device constant tables: must exist before a stream capture starts
 void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers& b, int32_t count, int32_t op_id,
                        int32_t hops, int32_t slots_bound, bool is_presc);
 void launch_find_feat(hipStream_t s, const int32_t* sampled_ids, int32_t* cache_offset, const int32_t* nc,
@@ -149,6 +157,10 @@ struct GPUMemoryPool {
     int32_t feature_rows = 0;         // capacity of the feature buffers in rows (0 = unbounded)
     unsigned long long* pos_map = nullptr; // u64[V], see kernels.hip "position table"
     uint32_t batch_serial = 0;        // batches started on this pool; epoch = 0xFFFFFFFF - serial
+    legion::BatchCtl* ctl = nullptr;  // device copy of (batch cursor, epoch): what the kernels read
+    bool capturing = false;           // between Begin/EndBatchCapture: launchers record a self-driven batch
+    bool ctl_synced = false;          // ctl holds (ctl_counter, epoch of the NEXT batch): a batch graph can run as is
+    int32_t ctl_counter = 0;
     int32_t* cand = nullptr;
     int32_t* aux = nullptr;
     int32_t* tile_edge = nullptr;

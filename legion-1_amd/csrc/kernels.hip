@@ -92,13 +92,29 @@ __device__ inline int32_t total_nodes(const int32_t* nc, int32_t hops) { return 
 // ------------------------------------------------------------------------------------------------
 // Kernel's `batch_size` is the launcher's clamped `size` -- the reference passes `size`
 // (Kernels.cu:227), so the read offset is size*counter (restated, not "fixed").
+// SELF (captured batch graphs): the batch cursor and the table epoch live in device memory (BatchCtl),
+// advanced by k_advance at the end of every graph launch, so that the captured launch has no per-batch
+// arguments.  Host-driven launches pass both as arguments and publish them for the kernels that follow.
+template <bool SELF>
 __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids, int32_t* __restrict__ labels,
-                                                 int32_t size, int32_t counter, const int32_t* __restrict__ all_ids,
+                                                 int32_t batch_size, int32_t size, int32_t counter,
+                                                 const int32_t* __restrict__ all_ids,
                                                  const int32_t* __restrict__ all_labels, int32_t total_cap,
                                                  unsigned long long* __restrict__ pos_map, uint32_t epoch,
-                                                 int32_t* __restrict__ nc, int32_t* __restrict__ ec)
+                                                 BatchCtl* __restrict__ ctl, int32_t* __restrict__ nc,
+                                                 int32_t* __restrict__ ec)
 {
     int32_t idx = threadIdx.x + blockDim.x * blockIdx.x;
+    if (SELF) {
+        counter = ctl->counter;
+        epoch = ctl->epoch;
+        // Kernels.cu:224 on the device (int64: counter is not bounded by the host here)
+        const int64_t done = (int64_t)batch_size * counter;
+        size = (done + batch_size >= total_cap) ? (int32_t)max((int64_t)0, min((int64_t)batch_size, (int64_t)total_cap - done)) : batch_size;
+    } else if (idx == 0) {
+        ctl->counter = counter;
+        ctl->epoch = epoch;
+    }
     if (idx < size) {
         int32_t g = size * counter + idx;
         if (g >= total_cap) {
@@ -127,6 +143,9 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
         ec[idx] = 0;
     }
 }
+__global__ void k_set_cursor(BatchCtl* ctl, int32_t counter, uint32_t epoch) { ctl->counter = counter; ctl->epoch = epoch; }
+// end of a captured batch: next batch, next (smaller) epoch
+__global__ void k_advance(BatchCtl* ctl) { ctl->counter += 1; ctl->epoch -= 1; }
 
 // S7: ClearPosMap (Kernels.cu:750-756) has no kernel here: position-table entries carry the batch epoch
 // in their upper 32 bits, so entries of older batches are simply stale (see the table format below).
@@ -145,7 +164,7 @@ struct SampleArgs {
     int32_t* aux;
     int32_t* tile_edge;
     unsigned long long* edge_access_time;
-    uint32_t epoch;
+    const BatchCtl* ctl;       // table epoch of the running batch
     const uint32_t* pow_tab;   // pow_tab[m] = 48271^(m+1), m < kTile
     uint32_t a_tile;           // 48271^kTile
     uint32_t a_step;           // 48271^(kTile * gridDim.x)
@@ -169,6 +188,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
     const int32_t* __restrict__ input = (a.op_id == 2) ? a.sampled_ids : a.agg_src_ids + a.ec[2];
     const int32_t n_tiles = (total + kTile - 1) / kTile;
     const int tid = threadIdx.x;
+    const uint32_t epoch = a.ctl->epoch;
 
     if ((int32_t)blockIdx.x >= n_tiles) return;
 
@@ -250,12 +270,12 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                 } else {
                     // claim: lowest idx wins.  A stale (larger) read only costs a redundant atomic.
                     // Entries of older batches have a larger epoch field, i.e. compare greater: unseen.
-                    const unsigned long long mine = ((unsigned long long)a.epoch << 32) | kProvisional | (uint32_t)idx;
+                    const unsigned long long mine = ((unsigned long long)epoch << 32) | kProvisional | (uint32_t)idx;
                     const unsigned long long cur = a.pos_map[dst];
                     if (cur > mine) atomicMin(a.pos_map + dst, mine);
                     // final positions are only written by earlier launches: if we see one it is exact,
                     // and k_mark need not probe the table for this slot again
-                    if (cur < (((unsigned long long)a.epoch << 32) | kProvisional)) known = (int32_t)(uint32_t)cur;
+                    if (cur < (((unsigned long long)epoch << 32) | kProvisional)) known = (int32_t)(uint32_t)cur;
                     // a smaller claim of this hop is already in the table: this slot has lost for good
                     // (claims only decrease).  Point at that slot; if it loses later too, its own aux
                     // points further, and k_resolve follows the chain to the winner.
@@ -292,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // survived is the winner of a new node.
 __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, const int32_t* __restrict__ ec,
                                                  int32_t count, const unsigned long long* __restrict__ pos_map,
-                                                 uint32_t epoch, int32_t* __restrict__ cand, int32_t* __restrict__ aux,
+                                                 int32_t* __restrict__ cand, int32_t* __restrict__ aux,
                                                  int32_t* __restrict__ tile_node, HopState* __restrict__ hs)
 {
     __shared__ int32_t s_cnt[kBlock / 64];
@@ -383,7 +403,7 @@ struct WriteArgs {
     unsigned long long* pos_map;
     FastDiv fdiv;
     int32_t op_id;
-    uint32_t epoch;
+    const BatchCtl* ctl;
     int32_t last_hop; // positions of the nodes found in the last hop are never looked up through the table
 };
 
@@ -394,6 +414,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
     __shared__ int32_t s_n[S * W];
     __shared__ int32_t s_pre[2][W];
     const HopState h = *a.hs;
+    const uint32_t epoch = a.ctl->epoch;
     const int32_t total = h.slots;
     const int32_t n_tiles = (total + kTile - 1) / kTile;
     const int lane = lane_id(), wave = wave_id();
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
                 // the winner publishes its position per SLOT (streamed store); the scattered table store
                 // is only needed when a later hop may look the node up by id
                 a.aux[idx] = p;
-                if (!a.last_hop) a.pos_map[dst] = ((unsigned long long)a.epoch << 32) | (uint32_t)p;
+                if (!a.last_hop) a.pos_map[dst] = ((unsigned long long)epoch << 32) | (uint32_t)p;
                 so = p;
             }
             a.agg_src_off[e] = so;
@@ -740,14 +761,27 @@ static uint32_t* pow_table()
     return tabs[dev];
 }
 
-void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t size, int32_t counter,
+void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t batch_size, int32_t size, int32_t counter,
                  const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
-                 uint32_t epoch, int32_t* nc, int32_t* ec)
+                 uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec)
 {
-    int blocks = size > 0 ? (size - 1) / kBlock + 1 : 1;
-    k_seed<<<blocks, kBlock, 0, s>>>(batch_ids, labels, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, nc, ec);
+    const int32_t bound = self_driven ? batch_size : size;
+    int blocks = bound > 0 ? (bound - 1) / kBlock + 1 : 1;
+    if (self_driven) k_seed<true><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec);
+    else k_seed<false><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec);
     HIP_CHECK_LAST();
 }
+void launch_set_cursor(hipStream_t s, BatchCtl* ctl, int32_t counter, uint32_t epoch)
+{
+    k_set_cursor<<<1, 1, 0, s>>>(ctl, counter, epoch);
+    HIP_CHECK_LAST();
+}
+void launch_advance(hipStream_t s, BatchCtl* ctl)
+{
+    k_advance<<<1, 1, 0, s>>>(ctl);
+    HIP_CHECK_LAST();
+}
+void warm_static_tables() { (void)pow_table(); (void)cu_count(); }
 
 void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers& b, int32_t count, int32_t op_id,
                        int32_t hops, int32_t slots_bound, bool is_presc)
@@ -760,7 +794,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     a.sampled_ids = b.sampled_ids; a.agg_src_ids = b.agg_src_ids; a.nc = b.nc; a.ec = b.ec;
     a.pos_map = b.pos_map; a.cand = b.cand; a.aux = b.aux; a.tile_edge = b.tile_edge;
     a.edge_access_time = b.edge_access_time;
-    a.epoch = b.epoch;
+    a.ctl = b.ctl;
     a.pow_tab = pow_table();
     a.a_tile = powmod31(kA, kTile);
     a.a_step = powmod31(kA, (uint64_t)kTile * (uint64_t)grid);
@@ -772,10 +806,10 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
     else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
-    k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.pos_map, b.epoch, b.cand, b.aux, b.tile_node, b.hop_state);
+    k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.pos_map, b.cand, b.aux, b.tile_node, b.hop_state);
     HIP_CHECK_LAST();
     WriteArgs w;
-    w.hs = b.hop_state; w.nc = b.nc; w.ec = b.ec; w.hops = hops; w.cand = b.cand; w.aux = b.aux; w.epoch = b.epoch; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
+    w.hs = b.hop_state; w.nc = b.nc; w.ec = b.ec; w.hops = hops; w.cand = b.cand; w.aux = b.aux; w.ctl = b.ctl; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
     w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
     w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id; w.last_hop = (op_id / 2 == hops) ? 1 : 0;
     k_write<<<grid, kBlock, 0, s>>>(w);

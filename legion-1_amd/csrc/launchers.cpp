@@ -58,6 +58,17 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
 
     GPUMemoryPool* p = memorypool;
     p->device_id = dev_id;
+    const int q = p->current_pipe;
+    if (p->capturing) {
+        // Recording a batch graph: cursor, epoch and the clamped size (Kernels.cu:224) are read / computed on the
+        // device, `counter` is ignored, bounds are those of a full batch.
+        if (batch_size > p->batch_size) { LEGION_ARG_ERROR("batch_generator_kernel: batch larger than the pool was sized for"); return; }
+        launch_seed(s, p->sampled_ids[q], p->labels[q], batch_size, batch_size, 0, all_ids, all_labels, total_cap, p->pos_map, 0,
+                    p->ctl, true, p->node_counter[q], p->edge_counter[q]);
+        p->bound_n = batch_size > 0 ? batch_size : 0;
+        p->bound_nodes = p->bound_n;
+        return;
+    }
     // A new batch = a new epoch of the position table: entries of older batches become stale without
     // touching them (replaces cudaMemsetAsync(accessed_map) + ClearPosMap, Kernels.cu:216,750-756).
     if (++p->batch_serial >= 0xFFFFFFF0u) { // epoch space exhausted: wipe once and start over
@@ -65,12 +76,12 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
         p->batch_serial = 1;
     }
     const uint32_t epoch = 0xFFFFFFFFu - p->batch_serial;
+    p->ctl_synced = false; // k_seed publishes (counter, epoch) of THIS batch: a batch graph must reset the cursor
     // Kernels.cu:224
     int32_t size = ((batch_size * (counter + 1)) >= total_cap) ? (total_cap - batch_size * counter) : batch_size;
     if (size > p->batch_size) { LEGION_ARG_ERROR("batch_generator_kernel: batch larger than the pool was sized for"); return; }
-    const int q = p->current_pipe;
-    launch_seed(s, p->sampled_ids[q], p->labels[q], size, counter, all_ids, all_labels, total_cap, p->pos_map, epoch,
-                p->node_counter[q], p->edge_counter[q]);
+    launch_seed(s, p->sampled_ids[q], p->labels[q], batch_size, size, counter, all_ids, all_labels, total_cap, p->pos_map, epoch,
+                p->ctl, false, p->node_counter[q], p->edge_counter[q]);
     p->bound_n = size > 0 ? size : 0;
     p->bound_nodes = p->bound_n;
 }
@@ -104,7 +115,7 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     const int q = p->current_pipe;
     b.sampled_ids = p->sampled_ids[q]; b.agg_src_ids = p->agg_src_ids; b.agg_src_off = p->agg_src_off[q];
     b.agg_dst_off = p->agg_dst_off[q]; b.nc = p->node_counter[q]; b.ec = p->edge_counter[q];
-    b.pos_map = p->pos_map; b.epoch = 0xFFFFFFFFu - p->batch_serial; b.cand = p->cand; b.aux = p->aux; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
+    b.pos_map = p->pos_map; b.ctl = p->ctl; b.cand = p->cand; b.aux = p->aux; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
     b.hop_state = p->hop_state; b.edge_access_time = nullptr;
     if (is_presc) {
         // kernel_pre_sampler_optimized: host CSR only + topology hotness (Kernels.cu:636-649)

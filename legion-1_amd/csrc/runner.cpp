@@ -29,6 +29,9 @@ struct Runner {
     std::vector<Operator*> op_factory;
     std::vector<OpParams*> op_params;
     int32_t feature_rows = 0;
+    // $LEGION_BATCH_GRAPH=1: RunOnce replays one recorded hipGraph per (pipe, mode) instead of launching the ops
+    bool use_graph = false;
+    LegionBatchGraph* graphs[LEGION_PIPELINE_DEPTH][3] = {};
 };
 
 extern "C" {
@@ -62,6 +65,7 @@ void Runner_Initialize(Runner* r, RunnerParams* params)
     r->op_factory[r->op_num - 1] = NewCacheUpdater(r->op_num - 1);
 
     r->pipeline_depth = LEGION_PIPELINE_DEPTH;
+    { const char* e = getenv("LEGION_BATCH_GRAPH"); r->use_graph = e && atoi(e) != 0; }
     const int total_num_nodes = GPUNodeStorage_TotalNodeNum(noder);
     GPUCache_InitializeCacheController(cache, r->local_dev_id, total_num_nodes);
     r->memorypool = NewGPUMemoryPool(r->pipeline_depth);
@@ -143,12 +147,29 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     GPUMemoryPool_SetCurrentMode(r->memorypool, r->mode);
     GPUMemoryPool_SetIter(r->memorypool, IPCEnv_GetLocalBatchId(env, batch_id));
     IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
-    for (int i = 0; i < r->op_num; i++) {
-        if (i % 2 == 1) HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[i - 1], 0));
-        r->op_params[i]->is_presc = 0;
-        Operator_run(r->op_factory[i], r->op_params[i]);
+    auto run_ops = [&]() {
+        for (int i = 0; i < r->op_num; i++) {
+            if (i % 2 == 1) HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[i - 1], 0));
+            r->op_params[i]->is_presc = 0;
+            Operator_run(r->op_factory[i], r->op_params[i]);
+        }
+    };
+    if (r->use_graph && r->mode >= 0 && r->mode < 3) {
+        LegionBatchGraph*& g = r->graphs[r->current_pipe][r->mode];
+        if (!g) { // record this (pipe, mode) once: stream 1 forks off through the op events and is joined back
+            if (GPUMemoryPool_BeginBatchCapture(r->memorypool, r->streams[0]) == 0) {
+                run_ops();
+                HIP_CHECK(hipStreamWaitEvent(r->streams[0], r->events[r->op_num - 1], 0));
+                g = GPUMemoryPool_EndBatchCapture(r->memorypool, r->streams[0]);
+            }
+            if (!g) { LEGION_ARG_ERROR("Runner_RunOnce: recording the batch graph failed"); return; }
+        }
+        LegionBatchGraph_Launch(g, r->streams[0], IPCEnv_GetLocalBatchId(env, batch_id));
+        HIP_CHECK(hipStreamSynchronize(r->streams[0]));
+    } else {
+        run_ops();
+        HIP_CHECK(hipEventSynchronize(r->events[r->op_num - 1])); // reference: spin on cudaEventQuery
     }
-    HIP_CHECK(hipEventSynchronize(r->events[r->op_num - 1])); // reference: spin on cudaEventQuery
     IPCEnv_IPCPost(env, r->local_dev_id, r->current_pipe);
     r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
     GPUMemoryPool_SetCurrentPipe(r->memorypool, r->current_pipe);
@@ -168,6 +189,7 @@ GPUMemoryPool* Runner_GetMemoryPool(Runner* r) { return r ? r->memorypool : null
 void Runner_Delete(Runner* r)
 {
     if (!r) return;
+    for (auto& pipe : r->graphs) for (auto& g : pipe) { LegionBatchGraph_Delete(g); g = nullptr; }
     for (auto op : r->op_factory) Operator_Delete(op);
     for (auto p : r->op_params) delete p;
     for (auto e : r->events) (void)hipEventDestroy(e);

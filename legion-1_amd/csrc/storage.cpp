@@ -465,6 +465,9 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     HIP_CHECK(hipMalloc(&p->pos_map, (size_t)total_num_nodes * sizeof(unsigned long long)));
     HIP_CHECK(hipMemset(p->pos_map, 0xFF, (size_t)total_num_nodes * sizeof(unsigned long long)));
     p->batch_serial = 0;
+    HIP_CHECK(hipMalloc(&p->ctl, sizeof(BatchCtl)));
+    { const BatchCtl c{0, 0xFFFFFFFFu}; HIP_CHECK(hipMemcpy(p->ctl, &c, sizeof(c), hipMemcpyHostToDevice)); }
+    p->ctl_synced = false;
     HIP_CHECK(hipMalloc(&p->cand, (size_t)p->max_slots * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->aux, (size_t)p->max_slots * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_edge, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
@@ -503,14 +506,14 @@ char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p) { return (char*)p->tmp
 int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p) { return p->tmp_part_off; }
 uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p) { return (uint64_t*)p->pos_map; }
 uint32_t GPUMemoryPool_GetBatchSerial(const GPUMemoryPool* p) { return p->batch_serial; }
-void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial) { p->batch_serial = serial; }
+void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial) { p->batch_serial = serial; p->ctl_synced = false; }
 
 void GPUMemoryPool_Finalize(GPUMemoryPool* p)
 {
     if (!p || !p->owns_scratch) return;
     (void)hipFree(p->pos_map); (void)hipFree(p->cand); (void)hipFree(p->aux); p->aux = nullptr; (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
     (void)hipFree(p->hop_state); (void)hipFree(p->cache_search_buffer); (void)hipFree(p->agg_src_ids);
-    (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off);
+    (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off); (void)hipFree(p->ctl); p->ctl = nullptr;
     p->pos_map = nullptr; p->cand = nullptr; p->tile_edge = p->tile_node = nullptr; p->hop_state = nullptr;
     p->cache_search_buffer = p->agg_src_ids = p->tmp_part_off = nullptr; p->tmp_part_ind = nullptr;
     p->owns_scratch = false;

@@ -162,6 +162,53 @@ def test_back_to_back_batches_without_planner(K, oracle, small_ds):
     eng.close()
 
 
+def test_batch_graph_replay_matches_oracle(K, oracle, small_ds):
+    """One mini-batch recorded as a hipGraph per pipe (device-resident batch cursor + table epoch) and replayed:
+    consecutive batches, a jump in the cursor, a host-driven batch in between, the short last batch of the seed
+    list (the size clamp of Kernels.cu:224 computed on the device) and the -1 padded batch after it."""
+    ds = small_ds
+    B, fan = 200, [10, 5]
+    L = K.lib()
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan, pipeline_depth=2)
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    graphs = [eng.capture_batch(0, pipe=q) for q in (0, 1)]
+    last = (len(ds.train) - 1) // B               # B * (last + 1) >= n_train: short batch
+    assert 0 < len(ds.train) - B * last <= B
+    plan = [("g", 0), ("g", 1), ("g", 2), ("h", 3), ("g", 4), ("g", 7), ("g", 8), ("g", last), ("g", 0), ("h", 1), ("g", 2)]
+    serial0 = L.GPUMemoryPool_GetBatchSerial(eng.pools[0])
+    for n, (how, it) in enumerate(plan):
+        q = n % 2
+        ref = orc.run_batch(ds.train, ds.labels[ds.train], it)
+        if how == "g":
+            eng.run_graph(graphs[q], it)
+        else:
+            eng.run_batch(0, it, pipe=q, stream=graphs[q][1])
+        assert_batch_equal(ref, eng.result(0, pipe=q))
+    assert L.GPUMemoryPool_GetBatchSerial(eng.pools[0]) == serial0 + len(plan)   # one table epoch per batch, either way
+    eng.close()
+
+
+def test_batch_graph_one_gather_and_three_hops(K, oracle, small_ds):
+    """Graph of the bench's schedule (3 hops, one gather over all levels, no planner), back to back without syncs."""
+    ds = small_ds
+    B, fan = 300, [10, 5, 3]
+    L = K.lib()
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan, pipeline_depth=2)
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    st = L.d_stream_create()
+    graphs = [eng.capture_batch(0, pipe=q, per_level=False, plan=False, stream=st) for q in (0, 1)]
+    for it in range(0, 6, 2):                      # two batches in flight on one stream, then compare both pipes
+        eng.run_graph(graphs[0], it, sync=False)
+        eng.run_graph(graphs[1], it + 1, sync=True)
+        for q in (0, 1):
+            ref = orc.run_batch(ds.train, ds.labels[ds.train], it + q)
+            assert_batch_equal(ref, eng.result(0, pipe=q))
+    eng.close()
+    L.d_stream_destroy(st)
+
+
 def test_operator_plugin_api(K, oracle, small_ds):
     """The reference's Operator objects (Operator.h:4-27) driven the way GPURunner::RunOnce does."""
     ds = small_ds

@@ -49,6 +49,10 @@ def parse():
                          "reference's UVA configuration (GPUGraphStore.cu:315); combine with --cache unified for an HBM cache")
     ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
+    ap.add_argument("--cu-split", type=int, default=0, help="experiment (overlap schedule): of every 8 compute units, this many run "
+                    "the sampler stream and the rest the gather stream (hipExtStreamCreateWithCUMask); 0 = unrestricted streams")
+    ap.add_argument("--cu-pattern", default="mod", choices=["mod", "block"], help="--cu-split: bit i belongs to the sampler if "
+                    "i %% 8 < S (mod) or (i // 32) %% 8 < S (block)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
     return ap.parse_args()
@@ -155,8 +159,17 @@ def main():
         cache_info = build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev)
     else:
         L.GPUCache_SetPreSc(eng.cache, 0)  # steady state: no pre-sampling epoch in the all-resident configuration
-    stream = L.d_stream_create()       # sampler stream
-    gstream2 = L.d_stream_create()     # gather stream of the overlapped schedule (reference: streams_[1], Server.cu:178-181)
+    if args.cu_split > 0:
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (n_cu + 31) // 32
+        owner = [(i % 8 if args.cu_pattern == "mod" else (i // 32) % 8) < args.cu_split for i in range(words * 32)]
+        m_s = np.array([sum(1 << b for b in range(32) if owner[w * 32 + b] and w * 32 + b < n_cu) for w in range(words)], dtype=np.uint32)
+        m_g = np.array([sum(1 << b for b in range(32) if not owner[w * 32 + b] and w * 32 + b < n_cu) for w in range(words)], dtype=np.uint32)
+        stream = L.d_stream_create_cu_mask(m_s.ctypes.data, words)
+        gstream2 = L.d_stream_create_cu_mask(m_g.ctypes.data, words)
+    else:
+        stream = L.d_stream_create()       # sampler stream
+        gstream2 = L.d_stream_create()     # gather stream of the overlapped schedule (reference: streams_[1], Server.cu:178-181)
     steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
     K_steps, W = args.steps, args.warmup
 

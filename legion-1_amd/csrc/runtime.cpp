@@ -130,6 +130,13 @@ void* d_stream_create(void)
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return (void*)s;
 }
+void* d_stream_create_cu_mask(const uint32_t* cu_mask, int32_t words)
+{   // a stream whose kernels only run on the CUs whose bit is set (hipExtStreamCreateWithCUMask)
+    hipStream_t s = nullptr;
+    if (!cu_mask || words <= 0) { LEGION_ARG_ERROR("d_stream_create_cu_mask: empty mask"); return nullptr; }
+    HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask));
+    return (void*)s;
+}
 void d_stream_destroy(void* stream) { (void)hipStreamDestroy((hipStream_t)stream); }
 void d_copy_async(void* dst, const void* src, int64_t num_bytes, void* stream)
 {

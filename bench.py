@@ -49,6 +49,8 @@ def parse():
                          "reference's UVA configuration (GPUGraphStore.cu:315); combine with --cache unified for an HBM cache")
     ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
+    ap.add_argument("--stream-priority", default="none", choices=["none", "sampler", "gather"],
+                    help="overlap schedule: which of the two streams gets the high stream priority (the other the low one)")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment (overlap schedule): of every 8 compute units, this many run "
                     "the sampler stream and the rest the gather stream (hipExtStreamCreateWithCUMask); 0 = unrestricted streams")
     ap.add_argument("--cu-pattern", default="mod", choices=["mod", "block"], help="--cu-split: bit i belongs to the sampler if "
@@ -167,6 +169,9 @@ def main():
         m_g = np.array([sum(1 << b for b in range(32) if not owner[w * 32 + b] and w * 32 + b < n_cu) for w in range(words)], dtype=np.uint32)
         stream = L.d_stream_create_cu_mask(m_s.ctypes.data, words)
         gstream2 = L.d_stream_create_cu_mask(m_g.ctypes.data, words)
+    elif args.stream_priority != "none":
+        stream = L.d_stream_create_priority(1 if args.stream_priority == "sampler" else 0)
+        gstream2 = L.d_stream_create_priority(1 if args.stream_priority == "gather" else 0)
     else:
         stream = L.d_stream_create()       # sampler stream
         gstream2 = L.d_stream_create()     # gather stream of the overlapped schedule (reference: streams_[1], Server.cu:178-181)

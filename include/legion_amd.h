@@ -80,6 +80,8 @@ void d_copy_h_2_d(void* d_ptr, const void* h_ptr, int64_t num_bytes);
 void d_copy_d_2_h(void* h_ptr, const void* d_ptr, int64_t num_bytes);
 void d_stream_sync(void* stream);
 void* d_stream_create(void);
+/* stream at the greatest (high != 0) or least priority of the device's range (hipStreamCreateWithPriority) */
+void* d_stream_create_priority(int32_t high);
 /* stream restricted to the compute units whose bit is set in cu_mask[words] (hipExtStreamCreateWithCUMask):
  * lets the two streams of the overlapped schedule own disjoint CU sets */
 void* d_stream_create_cu_mask(const uint32_t* cu_mask, int32_t words);

@@ -66,6 +66,7 @@ _SIGS = {
     "d_stream_sync": (None, [vp]),
     "d_stream_create": (vp, []),
     "d_stream_create_cu_mask": (vp, [vp, i32]),
+    "d_stream_create_priority": (vp, [i32]),
     "d_stream_destroy": (None, [vp]),
     "d_copy_async": (None, [vp, vp, i64, vp]),
     "d_memset_async": (None, [vp, C.c_int, i64, vp]),

@@ -130,6 +130,14 @@ void* d_stream_create(void)
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return (void*)s;
 }
+void* d_stream_create_priority(int32_t high)
+{   // high != 0: greatest priority of the device's range, else the least
+    hipStream_t s = nullptr;
+    int least = 0, greatest = 0;
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high ? greatest : least));
+    return (void*)s;
+}
 void* d_stream_create_cu_mask(const uint32_t* cu_mask, int32_t words)
 {   // a stream whose kernels only run on the CUs whose bit is set (hipExtStreamCreateWithCUMask)
     hipStream_t s = nullptr;

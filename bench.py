@@ -49,6 +49,7 @@ def parse():
                          "reference's UVA configuration (GPUGraphStore.cu:315); combine with --cache unified for an HBM cache")
     ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
+    ap.add_argument("--headline-only", action="store_true", help="skip the alt_schedule and graph_replay legs (clean kernel profiles)")
     ap.add_argument("--stream-priority", default="none", choices=["none", "sampler", "gather"],
                     help="overlap schedule: which of the two streams gets the high stream priority (the other the low one)")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment (overlap schedule): of every 8 compute units, this many run "
@@ -293,7 +294,7 @@ def main():
 
     # the other schedule on the very same K batches (reported beside the headline, never instead of it)
     alt = None
-    if not per_level and not intra:
+    if not per_level and not intra and not args.headline_only:
         if world > 1:
             torch.distributed.barrier()
         t_alt = time.perf_counter()
@@ -310,7 +311,7 @@ def main():
 
     # the serial schedule again, recorded once as a hipGraph and replayed with one launch per batch (same K batches)
     graph_leg = None
-    if not per_level and not intra:
+    if not per_level and not intra and not args.headline_only:
         L.GPUMemoryPool_SetCurrentPipe(pool, 0)
         hgraph = eng.capture_batch(me, pipe=0, per_level=False, plan=True, stream=stream)
         eng.run_graph(hgraph, W % steps_avail, sync=True)

@@ -8,6 +8,7 @@ import subprocess
 import sys
 import time
 
+import numpy as np
 import pytest
 
 from conftest import ROOT, sha
@@ -141,3 +142,40 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
             assert rec["n"] == ref["nc"][5 + 2 * H]
             assert rec["ids"] == sha(ref["ids"]) and rec["features"] == sha(ref["features"]) and rec["labels"] == sha(ref["labels"])
             assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
+
+
+def test_torch_trainer_learns_from_served_batches(tmp_path, synth):
+    """examples/legion_sage_torch.py (the reference trainer's loop, legion_graphsage.py:72-172, with a DGL-free mean
+    aggregator) against the server binary: labels are made recoverable from the features, so a few dozen steps on
+    the served blocks must beat chance (1/47) by a wide margin -- ids, features, labels and COO blocks are consistent."""
+    spec = synth.spec_for("products", scale=0.02)
+    ds = synth.generate(spec)
+    ds.features[np.arange(spec.V), ds.labels % spec.F] += 3.0
+    data = str(tmp_path / "ds") + "/"
+    synth.write_legion_files(ds, data)
+    B, epochs, fan = 512, 6, [10, 5]
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write(synth.meta_config_line(ds, data, B, 1 << 40, epochs, 0))
+    ns = "tr_%d_" % os.getpid()
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_BATCH_GRAPH="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "legion-1_amd", "ipc_service"), os.environ.get("PYTHONPATH", "")]))
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([SERVER, "1", "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,
+                                  env=env, cwd=str(tmp_path))
+    try:
+        _wait_ready(server, log)
+        tr = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "legion_sage_torch.py"), "--features_num", str(spec.F),
+                             "--class_num", str(spec.classes), "--hidden_dim", "64", "--learning_rate", "0.01", "--drop_rate", "0.1",
+                             "--epoch", str(epochs)], env=env, capture_output=True, text=True, timeout=600)
+        assert tr.returncode == 0, tr.stdout[-2000:] + tr.stderr[-3000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        if server.poll() is None:
+            server.kill()
+    lines = [l for l in tr.stdout.splitlines() if l.startswith("Epoch:")]
+    assert len(lines) == epochs, tr.stdout
+    acc = float(tr.stdout.split("Accuracy on test data:")[1].split()[0])
+    assert acc > 0.3, tr.stdout

@@ -179,3 +179,40 @@ def test_torch_trainer_learns_from_served_batches(tmp_path, synth):
     assert len(lines) == epochs, tr.stdout
     acc = float(tr.stdout.split("Accuracy on test data:")[1].split()[0])
     assert acc > 0.3, tr.stdout
+
+
+def test_torch_link_prediction_trainer_on_triple_seeds(tmp_path, synth):
+    """lp_sage.py's loop (three thirds [src | pos | neg] per batch, lp_sage.py:87-90) on a `trainingset` written by
+    synth.lp_trainingset.  Positives are neighbours (skewed towards hot = small ids), negatives uniform ids; one
+    feature channel tells how hot a node is, so the pairwise loss must fall below its untrained value 2 ln 2."""
+    spec = synth.spec_for("products", scale=0.02)
+    ds = synth.generate(spec)
+    ds.features[:, 0] = 3.0 * (1.0 - (np.arange(spec.V) / spec.V) ** (1.0 / 3.0))
+    B, epochs, fan = 513, 4, [10, 5]
+    ds.train = synth.lp_trainingset(ds, 171 * 12, B)          # 12 full batches of 171 triples
+    ds.spec = __import__("dataclasses").replace(ds.spec, n_train=len(ds.train))
+    data = str(tmp_path / "ds") + "/"
+    synth.write_legion_files(ds, data)
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write(synth.meta_config_line(ds, data, B, 1 << 40, epochs, 0))
+    ns = "lp_%d_" % os.getpid()
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "legion-1_amd", "ipc_service"), os.environ.get("PYTHONPATH", "")]))
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([SERVER, "1", "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,
+                                  env=env, cwd=str(tmp_path))
+    try:
+        _wait_ready(server, log)
+        tr = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "legion_sage_torch.py"), "--task", "lp", "--features_num",
+                             str(spec.F), "--class_num", "32", "--hidden_dim", "64", "--learning_rate", "0.01", "--drop_rate", "0.0",
+                             "--epoch", str(epochs)], env=env, capture_output=True, text=True, timeout=600)
+        assert tr.returncode == 0, tr.stdout[-2000:] + tr.stderr[-3000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        if server.poll() is None:
+            server.kill()
+    losses = [float(l.split("Train Loss:")[1].split(",")[0]) for l in tr.stdout.splitlines() if l.startswith("Epoch:")]
+    assert len(losses) == epochs and losses[-1] < 1.2 < 2 * np.log(2) + 0.2, tr.stdout

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GraphSAGE trainer on top of the sampling server, plain PyTorch (no DGL).
+"""GraphSAGE / GCN trainer on top of the sampling server, plain PyTorch (no DGL).
 
 Consumes mini-batches from the `legion` server through `ipc_service` exactly like the reference trainer
 (pytorch_extension/legion_graphsage.py:72-172): one process per GPU, `ipc_service.get_next(F)` ->
@@ -46,11 +46,29 @@ class SageMean(nn.Module):
         return self.fc_self(h[:num_dst]) + self.fc_neigh(agg) + self.bias
 
 
+class GraphConvBoth(nn.Module):
+    """DGL GraphConv(norm='both', allow_zero_in_degree=True) as legion_gcn.py:80-87 uses it:
+    h_dst = sum_{(s,d)} h_s / sqrt(outdeg_s * indeg_d) W + b, degrees counted inside the block and clamped to >= 1."""
+
+    def __init__(self, in_feats, out_feats):
+        super().__init__()
+        self.fc = nn.Linear(in_feats, out_feats, bias=True)
+
+    def forward(self, block, h):
+        src, dst, num_src, num_dst = block
+        one = torch.ones_like(src, dtype=h.dtype)
+        out_deg = torch.zeros(num_src, dtype=h.dtype, device=h.device).index_add_(0, src, one).clamp(min=1)
+        in_deg = torch.zeros(num_dst, dtype=h.dtype, device=h.device).index_add_(0, dst, one).clamp(min=1)
+        m = (h * out_deg.rsqrt().unsqueeze(1)).index_select(0, src)
+        agg = torch.zeros(num_dst, h.shape[1], dtype=h.dtype, device=h.device).index_add_(0, dst, m)
+        return self.fc(agg * in_deg.rsqrt().unsqueeze(1))
+
+
 class SAGE(nn.Module):
-    def __init__(self, in_feats, n_hidden, n_classes, n_layers, dropout):
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, dropout, conv=SageMean):
         super().__init__()
         dims = [in_feats] + [n_hidden] * (n_layers - 1) + [n_classes]
-        self.layers = nn.ModuleList(SageMean(dims[i], dims[i + 1]) for i in range(n_layers))
+        self.layers = nn.ModuleList(conv(dims[i], dims[i + 1]) for i in range(n_layers))
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, blocks, x):
@@ -81,7 +99,8 @@ def worker(rank, world, args):
     ipc_service.initialize()
     train_steps, valid_steps, test_steps = ipc_service.get_steps()
     hops = ipc_service.get_hops() if hasattr(ipc_service, "get_hops") else 2
-    model = SAGE(args.features_num, args.hidden_dim, args.class_num, hops, args.drop_rate).to(device)
+    model = SAGE(args.features_num, args.hidden_dim, args.class_num, hops, args.drop_rate,
+                 conv=GraphConvBoth if args.model == "gcn" else SageMean).to(device)
     if world > 1:
         model = DDP(model, device_ids=[rank])
     opt = torch.optim.Adam(model.parameters(), lr=args.learning_rate)
@@ -143,6 +162,7 @@ def worker(rank, world, args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser("Train GraphSAGE on batches of the Legion server (plain PyTorch).")
+    ap.add_argument("--model", default="sage", choices=["sage", "gcn"], help="legion_graphsage.py | legion_gcn.py layer")
     ap.add_argument("--task", default="nc", choices=["nc", "lp"], help="node classification | link prediction (lp_sage.py)")
     ap.add_argument("--class_num", type=int, default=47, help="nc: classes; lp: embedding width")
     ap.add_argument("--features_num", type=int, default=100)

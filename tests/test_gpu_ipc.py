@@ -144,7 +144,8 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
             assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
 
 
-def test_torch_trainer_learns_from_served_batches(tmp_path, synth):
+@pytest.mark.parametrize("model", ["sage", "gcn"])
+def test_torch_trainer_learns_from_served_batches(tmp_path, synth, model):
     """examples/legion_sage_torch.py (the reference trainer's loop, legion_graphsage.py:72-172, with a DGL-free mean
     aggregator) against the server binary: labels are made recoverable from the features, so a few dozen steps on
     the served blocks must beat chance (1/47) by a wide margin -- ids, features, labels and COO blocks are consistent."""
@@ -157,7 +158,7 @@ def test_torch_trainer_learns_from_served_batches(tmp_path, synth):
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
         f.write(synth.meta_config_line(ds, data, B, 1 << 40, epochs, 0))
-    ns = "tr_%d_" % os.getpid()
+    ns = "tr%s_%d_" % (model, os.getpid())
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_BATCH_GRAPH="1",
                PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "legion-1_amd", "ipc_service"), os.environ.get("PYTHONPATH", "")]))
     log = str(tmp_path / "server.log")
@@ -168,7 +169,7 @@ def test_torch_trainer_learns_from_served_batches(tmp_path, synth):
         _wait_ready(server, log)
         tr = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "legion_sage_torch.py"), "--features_num", str(spec.F),
                              "--class_num", str(spec.classes), "--hidden_dim", "64", "--learning_rate", "0.01", "--drop_rate", "0.1",
-                             "--epoch", str(epochs)], env=env, capture_output=True, text=True, timeout=600)
+                             "--epoch", str(epochs), "--model", model], env=env, capture_output=True, text=True, timeout=600)
         assert tr.returncode == 0, tr.stdout[-2000:] + tr.stderr[-3000:]
         server.wait(timeout=60)
         assert server.returncode == 0, open(log).read()[-3000:]
@@ -178,7 +179,11 @@ def test_torch_trainer_learns_from_served_batches(tmp_path, synth):
     lines = [l for l in tr.stdout.splitlines() if l.startswith("Epoch:")]
     assert len(lines) == epochs, tr.stdout
     acc = float(tr.stdout.split("Accuracy on test data:")[1].split()[0])
-    assert acc > 0.3, tr.stdout
+    losses = [float(l.split("Train Loss:")[1].split(",")[0]) for l in lines]
+    if model == "sage":
+        assert acc > 0.3, tr.stdout
+    else:   # GraphConv has no self term: a node's own (label-bearing) features never reach its output; the loss still falls
+        assert np.isfinite(losses).all() and losses[-1] < losses[0], tr.stdout
 
 
 def test_torch_link_prediction_trainer_on_triple_seeds(tmp_path, synth):

@@ -80,7 +80,11 @@ struct SamplerBuffers {
     unsigned long long* pos_map; // u64[V]: (epoch << 32) | value
     const BatchCtl* ctl;    // ctl->epoch = 0xFFFFFFFF - batch serial: newer batches compare smaller
     int32_t* cand;          // i32[max slots of a hop]
-    int32_t* aux;           // i32[max slots of a hop]: known final position or -1
+    int32_t* aux;           // i32[max slots of a hop], slot state: -1 claim pending / won, >= 0 known position, <= -2 lost to slot -2-x
+    int32_t* aux_next;      // the other buffer: k_resolve prepares it (-1) for the next hop
+    int32_t next_count;     // fan-out of the next hop (0: none)
+    int32_t aux_cap;        // elements per aux buffer
+    bool aux_prepared;      // aux already holds -1 for nc[2] * count slots
     int32_t* tile_edge;     // i32[max tiles]
     int32_t* tile_node;     // i32[max tiles]
     HopState* hop_state;
@@ -89,7 +93,8 @@ struct SamplerBuffers {
 
 void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t batch_size, int32_t size, int32_t counter,
                  const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
-                 uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec);
+                 uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec, int32_t* aux_next,
+                 int32_t f_next, int32_t aux_cap);
 void launch_set_cursor(hipStream_t s, BatchCtl* ctl, int32_t counter, uint32_t epoch);
 void launch_advance(hipStream_t s, BatchCtl* ctl);
 void warm_static_tables();   // per-device constant tables: must exist before a stream capture starts
@@ -162,7 +167,8 @@ struct GPUMemoryPool {
     bool ctl_synced = false;          // ctl holds (ctl_counter, epoch of the NEXT batch): a batch graph can run as is
     int32_t ctl_counter = 0;
     int32_t* cand = nullptr;
-    int32_t* aux = nullptr;
+    int32_t* aux2[2] = {nullptr, nullptr}; // slot states, one buffer per hop parity (hop h uses aux2[h & 1])
+    int32_t aux_ready_hop = 0, aux_ready_count = 0; // the launch before prepared aux2[hop & 1] for this fan-out
     int32_t* tile_edge = nullptr;
     int32_t* tile_node = nullptr;
     legion::HopState* hop_state = nullptr;

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
                                                  const int32_t* __restrict__ all_labels, int32_t total_cap,
                                                  unsigned long long* __restrict__ pos_map, uint32_t epoch,
                                                  BatchCtl* __restrict__ ctl, int32_t* __restrict__ nc,
-                                                 int32_t* __restrict__ ec)
+                                                 int32_t* __restrict__ ec, int32_t* __restrict__ aux_next,
+                                                 int32_t f_next, int32_t aux_cap)
 {
     int32_t idx = threadIdx.x + blockDim.x * blockIdx.x;
     if (SELF) {
@@ -142,6 +143,15 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
         nc[idx] = nv;
         ec[idx] = 0;
     }
+    // slot states of hop 1 start as "claim pending" (-1), see k_sample
+    const int64_t n_init = min((int64_t)max(size, 0) * f_next, (int64_t)aux_cap);
+    for (int64_t i = idx; i < n_init; i += (int64_t)gridDim.x * blockDim.x) aux_next[i] = -1;
+}
+// fallback when a hop's fan-out differs from what the previous launch prepared the slot states for
+__global__ void k_fill_aux(const int32_t* __restrict__ nc, int32_t count, int32_t* __restrict__ aux, int32_t aux_cap)
+{
+    const int64_t n = min((int64_t)nc[2] * count, (int64_t)aux_cap);
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) aux[i] = -1;
 }
 __global__ void k_set_cursor(BatchCtl* ctl, int32_t counter, uint32_t epoch) { ctl->counter = counter; ctl->epoch = epoch; }
 // end of a captured batch: next batch, next (smaller) epoch
@@ -268,24 +278,39 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                 if (dup) {
                     known = -2 - (idx - dup);
                 } else {
-                    // claim: lowest idx wins.  A stale (larger) read only costs a redundant atomic.
-                    // Entries of older batches have a larger epoch field, i.e. compare greater: unseen.
-                    const unsigned long long mine = ((unsigned long long)epoch << 32) | kProvisional | (uint32_t)idx;
-                    const unsigned long long cur = a.pos_map[dst];
-                    if (cur > mine) atomicMin(a.pos_map + dst, mine);
-                    // final positions are only written by earlier launches: if we see one it is exact,
-                    // and k_mark need not probe the table for this slot again
-                    if (cur < (((unsigned long long)epoch << 32) | kProvisional)) known = (int32_t)(uint32_t)cur;
-                    // a smaller claim of this hop is already in the table: this slot has lost for good
-                    // (claims only decrease).  Point at that slot; if it loses later too, its own aux
-                    // points further, and k_resolve follows the chain to the winner.
+                    // claim: lowest idx wins.  Entries of older batches have a larger epoch field, i.e. compare
+                    // greater: unseen.  A stale (larger) pre-filter read only costs a redundant atomic.
+                    const unsigned long long prov0 = ((unsigned long long)epoch << 32) | kProvisional;
+                    const unsigned long long mine = prov0 | (uint32_t)idx;
+                    unsigned long long cur = a.pos_map[dst];
+                    if (cur > mine) {
+                        const unsigned long long old = atomicMin(a.pos_map + dst, mine);
+                        if (old > mine) {
+                            // the table holds this slot's claim now.  If it replaced a claim of this hop (a larger
+                            // slot that got there first), that slot has lost for good: tell it who beat it.  Its own
+                            // thread left aux at -1 (pending) and never writes it again, so this is the only store.
+                            if ((uint32_t)(old >> 32) == epoch) a.aux[(uint32_t)old & 0x7FFFFFFFu] = -2 - idx;
+                            cur = mine;
+                        } else {
+                            cur = old; // a smaller entry arrived between the load and the atomic: exact value
+                        }
+                    }
+                    // final positions are only written by earlier launches: if we see one it is exact
+                    if (cur < prov0) known = (int32_t)(uint32_t)cur;
+                    // a smaller claim of this hop is in the table: this slot has lost for good (claims only
+                    // decrease).  Point at that slot; if it loses later too, its own aux points further, and
+                    // k_resolve follows the chain to the winner.
                     else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & 0x7FFFFFFFu);
                 }
                 cnt++;
             }
             if (idx < tile_end) {
                 a.cand[idx] = dst;
-                a.aux[idx] = known;
+                // aux[idx] was initialised to -1 ("claim pending") by the previous launch.  A pending slot must not
+                // store here: the slot that replaces its claim writes aux[idx] from another XCD, and two L2s
+                // holding different dirty bytes for one address would be written back in no defined order.
+                if (dst < 0) a.aux[idx] = 0;            // no edge: never read as an edge, not counted as a winner
+                else if (known != -1) a.aux[idx] = known;
             }
         }
         // tile edge count
@@ -311,8 +336,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // an earlier hop / seed), else -1.  Only the other slots probe the table here: a slot whose claim
 // survived is the winner of a new node.
 __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, const int32_t* __restrict__ ec,
-                                                 int32_t count, const unsigned long long* __restrict__ pos_map,
-                                                 int32_t* __restrict__ cand, int32_t* __restrict__ aux,
+                                                 int32_t count, const int32_t* __restrict__ aux,
                                                  int32_t* __restrict__ tile_node, HopState* __restrict__ hs)
 {
     __shared__ int32_t s_cnt[kBlock / 64];
@@ -327,30 +351,12 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
         *hs = h;
     }
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // a slot whose state is still -1 after k_sample kept its claim: it discovered a new node
         int32_t cnt = 0;
-        int32_t c[kTile / kBlock];
-        unsigned long long v[kTile / kBlock];
 #pragma unroll
         for (int s = 0; s < kTile / kBlock; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            c[s] = -1;
-            if (idx < total && aux[idx] == -1) c[s] = cand[idx]; // known / already lost slots need no probe
-        }
-#pragma unroll
-        for (int s = 0; s < kTile / kBlock; s++) v[s] = (c[s] >= 0) ? pos_map[c[s]] : 0ull;
-#pragma unroll
-        for (int s = 0; s < kTile / kBlock; s++) {
-            const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            if (c[s] < 0) continue;
-            const uint32_t lo = (uint32_t)v[s];
-            if (lo == (kProvisional | (uint32_t)idx)) {
-                cand[idx] = (int32_t)((uint32_t)c[s] | 0x80000000u);
-                cnt++;
-            } else {
-                // lost the claim: the table names the winning slot of this hop (all claims are final once
-                // k_sample has finished).  Stash it: k_resolve then needs no table probe at all.
-                aux[idx] = -2 - (int32_t)(lo & 0x7FFFFFFFu);
-            }
+            if (idx < total && aux[idx] == -1) cnt++;
         }
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
         if (lane_id() == 0) s_cnt[wave_id()] = cnt;
@@ -431,16 +437,17 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
         for (int32_t t = threadIdx.x; t < tile; t += kBlock) { pre_e += a.tile_edge[t]; pre_n += a.tile_node[t]; }
         for (int o = 32; o > 0; o >>= 1) { pre_e += __shfl_xor(pre_e, o); pre_n += __shfl_xor(pre_n, o); }
         if (lane == 0) { s_pre[0][wave] = pre_e; s_pre[1][wave] = pre_n; }
-        int32_t c[S], re[S], rn[S];
+        int32_t c[S], ax[S], re[S], rn[S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
             c[s] = (idx < total) ? a.cand[idx] : -1;
+            ax[s] = (idx < total) ? a.aux[idx] : 0;
         }
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const bool valid = c[s] != -1;
-            const bool isnew = valid && c[s] < 0;
+            const bool isnew = ax[s] == -1; // the slot kept its claim (k_sample): a new node
             const unsigned long long be = __ballot(valid), bn = __ballot(isnew);
             re[s] = __popcll(be & lt);
             rn[s] = __popcll(bn & lt);
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             int32_t pe = 0, pn = 0;
             for (int q = 0; q < s * W + wave; q++) { pe += s_e[q]; pn += s_n[q]; }
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            const int32_t dst = (int32_t)((uint32_t)c[s] & 0x7FFFFFFFu);
+            const int32_t dst = c[s];
             const int32_t e = ebase + pe + re[s];
             a.agg_src_ids[e] = dst;
             // dst-side offset = position of the slot's source node; for hops > 1 the sources are the
@@ -474,8 +481,8 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             // hop 1: the seed's position.  That is i unless the seed list holds duplicates (link-prediction
             // triples), where the reference's position_map keeps the last occurrence -- read it (<= B*f probes).
             a.agg_dst_off[e] = (a.op_id == 2) ? (int32_t)(uint32_t)a.pos_map[a.sampled_ids[i]] : a.agg_src_off[h.in_off + i];
-            int32_t so = a.aux[idx]; // known position (>= 0) or -2 - <winning slot> (k_resolve reads that slot's aux)
-            if (c[s] < 0) {
+            int32_t so = ax[s]; // known position (>= 0), -2 - <winning slot> (k_resolve reads that slot's aux) or -1: winner
+            if (ax[s] == -1) {
                 const int32_t p = nbase + pn + rn[s];
                 a.sampled_ids[p] = dst;
                 // the winner publishes its position per SLOT (streamed store); the scattered table store
@@ -494,16 +501,21 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
 // k_write already stored it for known nodes and winners; an edge that lost its claim carries
 // -2 - <winning slot>, and that slot's aux now holds the winner's position.
 __global__ __launch_bounds__(kBlock) void k_resolve(const HopState* __restrict__ hs, const int32_t* __restrict__ aux,
-                                                    int32_t* __restrict__ agg_src_off)
+                                                    int32_t* __restrict__ agg_src_off, int32_t* __restrict__ aux_next,
+                                                    int32_t next_count, int32_t aux_cap)
 {
     const int32_t base = hs->edge_base, n = hs->n_edges;
-    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = threadIdx.x + (int64_t)blockDim.x * blockIdx.x;
+    for (int64_t i = t0; i < n; i += stride) {
         int32_t so = agg_src_off[base + i];
         if (so < -1) {
             do so = aux[-2 - so]; while (so < -1); // loser -> (earlier loser ->)* winner: short chains
             agg_src_off[base + i] = so;
         }
     }
+    // the next hop expands this hop's n edges: its slot states (the other aux buffer) start as "claim pending"
+    const int64_t n_init = min((int64_t)n * next_count, (int64_t)aux_cap);
+    for (int64_t i = t0; i < n_init; i += stride) aux_next[i] = -1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -763,12 +775,13 @@ static uint32_t* pow_table()
 
 void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t batch_size, int32_t size, int32_t counter,
                  const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
-                 uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec)
+                 uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec, int32_t* aux_next,
+                 int32_t f_next, int32_t aux_cap)
 {
     const int32_t bound = self_driven ? batch_size : size;
     int blocks = bound > 0 ? (bound - 1) / kBlock + 1 : 1;
-    if (self_driven) k_seed<true><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec);
-    else k_seed<false><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec);
+    if (self_driven) k_seed<true><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec, aux_next, f_next, aux_cap);
+    else k_seed<false><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec, aux_next, f_next, aux_cap);
     HIP_CHECK_LAST();
 }
 void launch_set_cursor(hipStream_t s, BatchCtl* ctl, int32_t counter, uint32_t epoch)
@@ -789,6 +802,10 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     if (count <= 0 || slots_bound <= 0) { LEGION_ARG_ERROR("GPU_Random_Sampling: empty hop"); return; }
     const int max_tiles = (slots_bound + kTile - 1) / kTile;
     const int grid = grid_for(max_tiles, 1, 8);
+    if (!b.aux_prepared) { // the previous launch prepared the slot states for another fan-out (or there was none)
+        k_fill_aux<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.nc, count, b.aux, b.aux_cap);
+        HIP_CHECK_LAST();
+    }
     SampleArgs a;
     a.csr = csr;
     a.sampled_ids = b.sampled_ids; a.agg_src_ids = b.agg_src_ids; a.nc = b.nc; a.ec = b.ec;
@@ -806,7 +823,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
     else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
-    k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.pos_map, b.cand, b.aux, b.tile_node, b.hop_state);
+    k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.aux, b.tile_node, b.hop_state);
     HIP_CHECK_LAST();
     WriteArgs w;
     w.hs = b.hop_state; w.nc = b.nc; w.ec = b.ec; w.hops = hops; w.cand = b.cand; w.aux = b.aux; w.ctl = b.ctl; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
@@ -814,7 +831,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id; w.last_hop = (op_id / 2 == hops) ? 1 : 0;
     k_write<<<grid, kBlock, 0, s>>>(w);
     HIP_CHECK_LAST();
-    k_resolve<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.hop_state, b.aux, b.agg_src_off);
+    k_resolve<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.hop_state, b.aux, b.agg_src_off, b.aux_next, b.next_count, b.aux_cap);
     HIP_CHECK_LAST();
 }
 

@@ -64,7 +64,8 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
         // device, `counter` is ignored, bounds are those of a full batch.
         if (batch_size > p->batch_size) { LEGION_ARG_ERROR("batch_generator_kernel: batch larger than the pool was sized for"); return; }
         launch_seed(s, p->sampled_ids[q], p->labels[q], batch_size, batch_size, 0, all_ids, all_labels, total_cap, p->pos_map, 0,
-                    p->ctl, true, p->node_counter[q], p->edge_counter[q]);
+                    p->ctl, true, p->node_counter[q], p->edge_counter[q], p->aux2[1], p->fanout[0], p->max_slots);
+        p->aux_ready_hop = 1; p->aux_ready_count = p->fanout[0];
         p->bound_n = batch_size > 0 ? batch_size : 0;
         p->bound_nodes = p->bound_n;
         return;
@@ -81,7 +82,8 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
     int32_t size = ((batch_size * (counter + 1)) >= total_cap) ? (total_cap - batch_size * counter) : batch_size;
     if (size > p->batch_size) { LEGION_ARG_ERROR("batch_generator_kernel: batch larger than the pool was sized for"); return; }
     launch_seed(s, p->sampled_ids[q], p->labels[q], batch_size, size, counter, all_ids, all_labels, total_cap, p->pos_map, epoch,
-                p->ctl, false, p->node_counter[q], p->edge_counter[q]);
+                p->ctl, false, p->node_counter[q], p->edge_counter[q], p->aux2[1], p->fanout[0], p->max_slots);
+    p->aux_ready_hop = 1; p->aux_ready_count = p->fanout[0]; // k_seed prepared the slot states of hop 1
     p->bound_n = size > 0 ? size : 0;
     p->bound_nodes = p->bound_n;
 }
@@ -115,7 +117,7 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     const int q = p->current_pipe;
     b.sampled_ids = p->sampled_ids[q]; b.agg_src_ids = p->agg_src_ids; b.agg_src_off = p->agg_src_off[q];
     b.agg_dst_off = p->agg_dst_off[q]; b.nc = p->node_counter[q]; b.ec = p->edge_counter[q];
-    b.pos_map = p->pos_map; b.ctl = p->ctl; b.cand = p->cand; b.aux = p->aux; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
+    b.pos_map = p->pos_map; b.ctl = p->ctl; b.cand = p->cand; b.aux = p->aux2[hop & 1]; b.aux_next = p->aux2[(hop + 1) & 1]; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
     b.hop_state = p->hop_state; b.edge_access_time = nullptr;
     if (is_presc) {
         // kernel_pre_sampler_optimized: host CSR only + topology hotness (Kernels.cu:636-649)
@@ -133,7 +135,11 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
             csr.topo_owner = cache->ctl[dev]->topo_owner; csr.topo_row = cache->ctl[dev]->topo_row;
         }
     }
+    b.aux_cap = p->max_slots;
+    b.aux_prepared = p->aux_ready_hop == hop && p->aux_ready_count == count;
+    b.next_count = hop < p->hops ? p->fanout[hop] : 0;
     launch_sample_hop((hipStream_t)strm_hdl, csr, b, count, op_id, p->hops, (int32_t)slots, is_presc != 0);
+    p->aux_ready_hop = hop + 1; p->aux_ready_count = b.next_count; // k_resolve prepared the next hop's slot states
     p->bound_n = (int32_t)slots;          // next hop expands every sampled edge endpoint
     p->bound_nodes += (int32_t)slots;
 }

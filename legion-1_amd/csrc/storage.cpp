@@ -469,7 +469,7 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     { const BatchCtl c{0, 0xFFFFFFFFu}; HIP_CHECK(hipMemcpy(p->ctl, &c, sizeof(c), hipMemcpyHostToDevice)); }
     p->ctl_synced = false;
     HIP_CHECK(hipMalloc(&p->cand, (size_t)p->max_slots * sizeof(int32_t)));
-    HIP_CHECK(hipMalloc(&p->aux, (size_t)p->max_slots * sizeof(int32_t)));
+    for (auto& a : p->aux2) HIP_CHECK(hipMalloc(&a, (size_t)p->max_slots * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_edge, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_node, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->hop_state, sizeof(HopState)));
@@ -511,7 +511,7 @@ void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial) { p->batch_
 void GPUMemoryPool_Finalize(GPUMemoryPool* p)
 {
     if (!p || !p->owns_scratch) return;
-    (void)hipFree(p->pos_map); (void)hipFree(p->cand); (void)hipFree(p->aux); p->aux = nullptr; (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
+    (void)hipFree(p->pos_map); (void)hipFree(p->cand); for (auto& a : p->aux2) { (void)hipFree(a); a = nullptr; } (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
     (void)hipFree(p->hop_state); (void)hipFree(p->cache_search_buffer); (void)hipFree(p->agg_src_ids);
     (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off); (void)hipFree(p->ctl); p->ctl = nullptr;
     p->pos_map = nullptr; p->cand = nullptr; p->tile_edge = p->tile_node = nullptr; p->hop_state = nullptr;

@@ -120,6 +120,8 @@ struct GatherArgs {
     float* dst;
     int32_t off_idx, size_idx;                // nc[] indices of (offset, size); off_idx < 0 => offset 0
     int32_t dst_rows;                         // capacity of dst in rows (<= 0: unbounded)
+    int32_t* rows_seen;                       // host-mapped word: the launch leaves its actual row count here (may be null)
+    int32_t rows_hint;                        // row count of an earlier launch of this kind (0: unknown)
 };
 void launch_gather(hipStream_t s, const GatherArgs& a, int32_t rows_bound);
 void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_t hops, unsigned long long* access,
@@ -163,6 +165,10 @@ struct GPUMemoryPool {
     unsigned long long* pos_map = nullptr; // u64[V], see kernels.hip "position table"
     uint32_t batch_serial = 0;        // batches started on this pool; epoch = 0xFFFFFFFF - serial
     legion::BatchCtl* ctl = nullptr;  // device copy of (batch cursor, epoch): what the kernels read
+    // Feedback for sizing the gather launches without a host round trip: pinned, device-mapped words the gather
+    // kernels write their actual row count to ([l] = level-l gather, [LEGION_MAX_HOPS + 1] = all rows of the batch);
+    // the host reads whatever an earlier batch left there.
+    int32_t* rows_seen = nullptr;
     bool capturing = false;           // between Begin/EndBatchCapture: launchers record a self-driven batch
     bool ctl_synced = false;          // ctl holds (ctl_counter, epoch of the NEXT batch): a batch graph can run as is
     int32_t ctl_counter = 0;

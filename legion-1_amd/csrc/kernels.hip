@@ -568,6 +568,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
     const int32_t C = g.F / VEC;
     const int64_t total = (int64_t)rows * C;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (g.rows_seen && blockIdx.x == 0 && threadIdx.x == 0) *g.rows_seen = rows; // launch-size feedback for later batches
     for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += stride * UNROLL) {
         const VT* src[UNROLL];
         VT val[UNROLL];
@@ -864,10 +865,17 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     a.div_c = FastDiv((uint32_t)C);
     // Tuned on MI355X (profiles/r01_gather_sweep.md): non-temporal loads and stores (rows are read once and
     // written once: keep them out of L2/MALL).
-    // One 16-byte chunk per lane and iteration, up to 512 workgroups per CU (131 072): the launch is sized
-    // by the static row bound, of which a batch typically fills 15-20 %, so a workgroup runs ~2 iterations.
-    // Measured best on MI355X (profiles/r01_gather_sweep.md): 333 us vs 340-365 us for 2048 persistent workgroups.
-    const int grid = grid_for((int64_t)rows_bound * C, kBlock, 512);
+    // One 16-byte chunk per lane and iteration.  Best measured with 2-3 iterations per lane: fewer workgroups
+    // run long serial loops, more leave most of the grid empty (profiles/r01_gather_sweep.md).  The static row
+    // bound is typically filled 15-60 %, so the grid is sized from the row count an earlier launch of this kind
+    // reported (rows_seen, no host round trip), + 25 %; without a report: the bound, at most 512 workgroups per CU.
+    int grid;
+    if (g.rows_hint > 0) {
+        const int64_t est = std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024);
+        grid = grid_for(est * C, kBlock * 3, 8192);
+    } else {
+        grid = grid_for((int64_t)rows_bound * C, kBlock, 512);
+    }
     if (vec4) k_gather<v4f, 1, 2><<<grid, kBlock, 0, s>>>(a);
     else k_gather<float, 1, 2><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();

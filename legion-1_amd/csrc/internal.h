@@ -168,7 +168,8 @@ struct GPUMemoryPool {
     // Feedback for sizing the gather launches without a host round trip: pinned, device-mapped words the gather
     // kernels write their actual row count to ([l] = level-l gather, [LEGION_MAX_HOPS + 1] = all rows of the batch);
     // the host reads whatever an earlier batch left there.
-    int32_t* rows_seen = nullptr;
+    int32_t* rows_seen = nullptr;      // host view
+    int32_t* rows_seen_dev = nullptr;  // device view of the same words
     bool capturing = false;           // between Begin/EndBatchCapture: launchers record a self-driven batch
     bool ctl_synced = false;          // ctl holds (ctl_counter, epoch of the NEXT batch): a batch graph can run as is
     int32_t ctl_counter = 0;

@@ -165,12 +165,10 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     g.size_idx = size_idx;
     g.dst_rows = p->feature_rows;
     g.rows_seen = nullptr; g.rows_hint = 0;
-    if (p->rows_seen) { // slot: level of a per-level gather, or the last one for "all rows of the batch"
+    if (p->rows_seen && p->rows_seen_dev) { // slot: level of a per-level gather, or the last one for "all rows of the batch"
         const int slot = off_idx < 0 ? LEGION_MAX_HOPS + 1 : (off_idx - 3) / 2;
-        int32_t* host_word = p->rows_seen + slot;
-        g.rows_hint = *(volatile int32_t*)host_word;
-        void* dev_word = nullptr;
-        if (hipHostGetDevicePointer(&dev_word, host_word, 0) == hipSuccess) g.rows_seen = (int32_t*)dev_word;
+        g.rows_hint = *(volatile int32_t*)(p->rows_seen + slot);
+        g.rows_seen = p->rows_seen_dev + slot;
     }
     if (cache && dev_id >= 0 && dev_id < cache->device_count && cache->ctl[dev_id]->feat_map && cache->ctl[dev_id]->node_capacity > 0 &&
         cache->d_shard_tab[dev_id]) {

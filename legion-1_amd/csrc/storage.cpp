@@ -470,6 +470,7 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     p->ctl_synced = false;
     HIP_CHECK(hipHostMalloc((void**)&p->rows_seen, (LEGION_MAX_HOPS + 2) * sizeof(int32_t), hipHostMallocMapped));
     memset(p->rows_seen, 0, (LEGION_MAX_HOPS + 2) * sizeof(int32_t));
+    HIP_CHECK(hipHostGetDevicePointer((void**)&p->rows_seen_dev, p->rows_seen, 0));
     HIP_CHECK(hipMalloc(&p->cand, (size_t)p->max_slots * sizeof(int32_t)));
     for (auto& a : p->aux2) HIP_CHECK(hipMalloc(&a, (size_t)p->max_slots * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_edge, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
@@ -515,7 +516,7 @@ void GPUMemoryPool_Finalize(GPUMemoryPool* p)
     if (!p || !p->owns_scratch) return;
     (void)hipFree(p->pos_map); (void)hipFree(p->cand); for (auto& a : p->aux2) { (void)hipFree(a); a = nullptr; } (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
     (void)hipFree(p->hop_state); (void)hipFree(p->cache_search_buffer); (void)hipFree(p->agg_src_ids);
-    (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off); (void)hipFree(p->ctl); p->ctl = nullptr; if (p->rows_seen) { (void)hipHostFree(p->rows_seen); p->rows_seen = nullptr; }
+    (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off); (void)hipFree(p->ctl); p->ctl = nullptr; if (p->rows_seen) { (void)hipHostFree(p->rows_seen); p->rows_seen = nullptr; p->rows_seen_dev = nullptr; }
     p->pos_map = nullptr; p->cand = nullptr; p->tile_edge = p->tile_node = nullptr; p->hop_state = nullptr;
     p->cache_search_buffer = p->agg_src_ids = p->tmp_part_off = nullptr; p->tmp_part_ind = nullptr;
     p->owns_scratch = false;

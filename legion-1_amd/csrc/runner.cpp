@@ -31,6 +31,13 @@ struct Runner {
     int32_t feature_rows = 0;
     // $LEGION_BATCH_GRAPH=1: RunOnce replays one recorded hipGraph per (pipe, mode) instead of launching the ops
     bool use_graph = false;
+    // Software pipelining of RunOnce (default; $LEGION_RUNNER_PIPELINE=0 = the reference's synchronous loop): the
+    // host enqueues batch i and only then waits for batch i-1 and posts its pipe, so the sampler of batch i
+    // (stream 0) overlaps the gathers of batch i-1 (stream 1) on the GPU.
+    bool pipelined = true;
+    bool pending = false;
+    int pending_pipe = 0;
+    hipEvent_t done_ev[LEGION_PIPELINE_DEPTH] = {};
     LegionBatchGraph* graphs[LEGION_PIPELINE_DEPTH][3] = {};
 };
 
@@ -66,6 +73,8 @@ void Runner_Initialize(Runner* r, RunnerParams* params)
 
     r->pipeline_depth = LEGION_PIPELINE_DEPTH;
     { const char* e = getenv("LEGION_BATCH_GRAPH"); r->use_graph = e && atoi(e) != 0; }
+    { const char* e = getenv("LEGION_RUNNER_PIPELINE"); r->pipelined = !(e && atoi(e) == 0); }
+    for (auto& ev : r->done_ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int total_num_nodes = GPUNodeStorage_TotalNodeNum(noder);
     GPUCache_InitializeCacheController(cache, r->local_dev_id, total_num_nodes);
     r->memorypool = NewGPUMemoryPool(r->pipeline_depth);
@@ -146,7 +155,21 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     r->mode = IPCEnv_GetCurrentMode(env, batch_id);
     GPUMemoryPool_SetCurrentMode(r->memorypool, r->mode);
     GPUMemoryPool_SetIter(r->memorypool, IPCEnv_GetLocalBatchId(env, batch_id));
-    IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
+    if (r->pending) {
+        // Pipelined loop: batch i-1 is in flight.  Wait for the trainer to free this pipe, but hand batch i-1 over
+        // the moment it is complete -- a trainer that is the bottleneck must not wait for our next enqueue.
+        while (IPCEnv_IPCTryWait(env, r->local_dev_id, r->current_pipe, 0) != 0) {
+            if (hipEventQuery(r->done_ev[r->pending_pipe]) == hipSuccess) {
+                IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+                r->pending = false;
+                IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
+                break;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(10));
+        }
+    } else {
+        IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
+    }
     auto run_ops = [&]() {
         for (int i = 0; i < r->op_num; i++) {
             if (i % 2 == 1) HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[i - 1], 0));
@@ -156,19 +179,40 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     };
     if (r->use_graph && r->mode >= 0 && r->mode < 3) {
         LegionBatchGraph*& g = r->graphs[r->current_pipe][r->mode];
-        if (!g) { // record this (pipe, mode) once: stream 1 forks off through the op events and is joined back
+        if (!g) { // record this (pipe, mode) once
             if (GPUMemoryPool_BeginBatchCapture(r->memorypool, r->streams[0]) == 0) {
-                run_ops();
-                HIP_CHECK(hipStreamWaitEvent(r->streams[0], r->events[r->op_num - 1], 0));
+                // recorded on ONE stream: a fork/join graph (gathers on stream 1) replays ~0.1 ms slower per batch
+                // than the plain launches on this runtime (examples/serve_bench.py), a linear one does not
+                for (int i = 0; i < r->op_num; i++) {
+                    OpParams op = *r->op_params[i];
+                    op.stream = r->streams[0];
+                    op.event = nullptr;
+                    op.is_presc = 0;
+                    Operator_run(r->op_factory[i], &op);
+                }
                 g = GPUMemoryPool_EndBatchCapture(r->memorypool, r->streams[0]);
             }
             if (!g) { LEGION_ARG_ERROR("Runner_RunOnce: recording the batch graph failed"); return; }
         }
         LegionBatchGraph_Launch(g, r->streams[0], IPCEnv_GetLocalBatchId(env, batch_id));
-        HIP_CHECK(hipStreamSynchronize(r->streams[0]));
+        if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[0]));
+        else HIP_CHECK(hipStreamSynchronize(r->streams[0]));
     } else {
         run_ops();
-        HIP_CHECK(hipEventSynchronize(r->events[r->op_num - 1])); // reference: spin on cudaEventQuery
+        // the updater (last op, stream 1) is ordered behind every op of the batch through the op events
+        if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[1]));
+        else HIP_CHECK(hipEventSynchronize(r->events[r->op_num - 1])); // reference: spin on cudaEventQuery
+    }
+    if (r->pipelined) {
+        if (r->pending) { // batch i is queued: now hand batch i-1 to its trainer
+            HIP_CHECK(hipEventSynchronize(r->done_ev[r->pending_pipe]));
+            IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+        }
+        r->pending = true;
+        r->pending_pipe = r->current_pipe;
+        r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
+        GPUMemoryPool_SetCurrentPipe(r->memorypool, r->current_pipe);
+        return;
     }
     IPCEnv_IPCPost(env, r->local_dev_id, r->current_pipe);
     r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
@@ -179,8 +223,13 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
 void Runner_Finalize(Runner* r, RunnerParams* params)
 {
     IPCEnv* env = (IPCEnv*)params->env;
-    IPCEnv_IPCWait(env, r->local_dev_id, (r->current_pipe + 1) % r->pipeline_depth);
     DeviceGuard guard(r->local_dev_id);
+    if (r->pending) { // the last batch of the pipelined loop
+        HIP_CHECK(hipEventSynchronize(r->done_ev[r->pending_pipe]));
+        IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+        r->pending = false;
+    }
+    IPCEnv_IPCWait(env, r->local_dev_id, (r->current_pipe + 1) % r->pipeline_depth);
     GPUMemoryPool_Finalize(r->memorypool);
 }
 
@@ -193,6 +242,7 @@ void Runner_Delete(Runner* r)
     for (auto op : r->op_factory) Operator_Delete(op);
     for (auto p : r->op_params) delete p;
     for (auto e : r->events) (void)hipEventDestroy(e);
+    for (auto e : r->done_ev) if (e) (void)hipEventDestroy(e);
     if (r->streams[0]) (void)hipStreamDestroy(r->streams[0]);
     if (r->streams[1]) (void)hipStreamDestroy(r->streams[1]);
     GPUMemoryPool_Delete(r->memorypool);

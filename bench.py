@@ -404,6 +404,8 @@ def main():
             "batches_per_s": round(K_steps * world / elapsed_max, 2),
             "edges_per_batch": round(job_edges / (K_steps * world), 1),
             "unique_nodes_per_batch": round(job_nodes / (K_steps * world), 1),
+            "sampler_algorithmic_bytes_per_batch": int(samp_bytes.mean()),   # 20 N_h + 28 E_h + 8 U_h summed over the hops
+            "gather_algorithmic_bytes_per_batch": int(gather_bytes.mean()),
             "graph_gen_s": round(gen_s, 2),
             "alt_schedule": alt,
             "graph_replay": graph_leg,

@@ -92,6 +92,8 @@ def worker(rank, world, args):
     import ipc_service
     torch.cuda.set_device(rank)
     device = torch.device("cuda", rank)
+    if args.seed is not None:
+        torch.manual_seed(args.seed)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "12355")
@@ -171,6 +173,7 @@ if __name__ == "__main__":
     ap.add_argument("--learning_rate", type=float, default=0.003)
     ap.add_argument("--epoch", type=int, default=100, help="must equal the epoch count in the server's meta_config")
     ap.add_argument("--gpu_num", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=None, help="torch.manual_seed (weights, dropout)")
     a = ap.parse_args()
     if a.gpu_num == 1:
         worker(0, 1, a)

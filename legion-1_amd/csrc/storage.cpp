@@ -447,6 +447,7 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
                                    const int32_t* fanout, int32_t hops)
 {
     if (!p || hops < 1 || hops > LEGION_MAX_HOPS || batch_size < 1 || total_num_nodes < 1) { LEGION_ARG_ERROR("GPUMemoryPool_AllocateScratch: bad arguments"); return; }
+    if (p->owns_scratch) GPUMemoryPool_Finalize(p); // re-sizing an initialised pool: release the old scratch first
     p->V = total_num_nodes; p->batch_size = batch_size; p->hops = hops;
     int64_t ids = batch_size, cur = batch_size, max_slots = 0;
     p->level_bound[0] = batch_size;

@@ -398,7 +398,8 @@ def test_gpu_generator_matches_numpy(K, synth):
     assert np.array_equal(tr.cpu().numpy(), ds.train)
 
 
-@pytest.mark.parametrize("workload,fan", [("products", [25, 10, 5]), ("papers100M", [25, 10, 5]), ("papers100M", [25, 10])])
+@pytest.mark.parametrize("workload,fan", [("products", [25, 10, 5]), ("papers100M", [25, 10, 5]), ("papers100M", [25, 10]),
+                                          ("uk-union", [25, 10, 5])])     # uk-union: E = 5.5e9 > 2^32 edge offsets, F = 256
 def test_full_size_properties(K, synth, workload, fan):
     """BASELINE.json sizes (V up to 111 M, ~64 GB resident): the oracle cannot run there in seconds,
     so check the size-independent properties every reference execution satisfies."""

@@ -247,7 +247,7 @@ def test_operator_plugin_api(K, oracle, small_ds):
 # ---------------------------------------------------------------------------------------------------
 # cache: pre-sampling, ranking, cost model, fill-up, unified cache with Kg logical GPUs on one device
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("G,mode,chunk_bytes", [(1, 0, None), (2, 1, None), (4, 2, 65536), (4, 1, 40000)])
+@pytest.mark.parametrize("G,mode,chunk_bytes", [(1, 0, None), (2, 1, None), (4, 2, 65536), (4, 1, 40000), (8, 3, None), (8, 2, 50000)])
 def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, monkeypatch):
     # chunk_bytes: force the cache shards to be split into several chunk allocations (default chunk: 1 GiB)
     if chunk_bytes is not None:
@@ -257,8 +257,8 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
     ds = small_ds
     V, F = ds.spec.V, ds.spec.F
     L = K.lib()
-    B, fan = 250, [10, 5]
-    Kg = {0: 1, 1: 2, 2: 4}[mode]
+    B, fan = (250 if G < 8 else 100), [10, 5]      # 8 partitions of the 1966 seeds hold 245 each
+    Kg = {0: 1, 1: 2, 2: 4, 3: 8}[mode]
     parts = oracle.split_seeds(ds.train, G)
     steps = min((len(p) - 1) // B for p in parts)
     counters = [500000, 250000]               # stand-ins for the two Intel-PCM PCIe counters (Server.cu:100)
@@ -352,7 +352,8 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
                 got = eng.result(g)
                 assert_batch_equal(ref, got)
                 hit = orcs[g].node_map[got["ids"]] >= 0
-                assert 0 < hit.sum() < len(hit)
+                # hits and misses both occur, unless the clique-wide cache (capacity x Kg) already holds nearly every node
+                assert 0 < hit.sum() and (hit.sum() < len(hit) or L.GPUCache_NodeCapacity(eng.cache, g) * Kg > 0.9 * V)
     eng.close()
 
 

@@ -619,3 +619,29 @@ def test_randomised_differential(K, oracle, seed):
         eng.run_batch(0, counter, per_level=bool(rng.randint(2)), plan=bool(rng.randint(2)))
         assert_batch_equal(ref, eng.result(0))
     eng.close()
+
+
+@pytest.mark.parametrize("V,B,fan", [(3000, 1000, [25, 10, 5]), (400, 400, [12, 12, 6, 3])])
+def test_heavy_duplicate_contention(K, oracle, V, B, fan):
+    """Far more slots than nodes (1.25 M slots over 3000 nodes: every node is claimed hundreds of times per hop from
+    every XCD): the who-beat-whom notifications, replaced claims and loser -> winner chains of k_sample / k_resolve are
+    exercised across thousands of concurrently running tiles.  HIP == oracle, bit for bit, on consecutive batches."""
+    rng = np.random.RandomState(V)
+    F = 8
+    deg = rng.randint(20, 60, size=V)
+    deg[rng.randint(0, V, size=V // 50)] = 0
+    indptr = np.zeros(V + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    indices = rng.randint(0, V, size=int(indptr[-1])).astype(np.int32)
+    indices[rng.rand(len(indices)) < 0.01] = -1
+    feats = rng.rand(V, F).astype(np.float32)
+    labels = rng.randint(0, 5, size=V).astype(np.int32)
+    seeds = rng.permutation(V)[:min(V, 3 * B)].astype(np.int32)
+    orc = oracle.OracleRunner(indptr, indices, feats, V, F, B, fan)
+    eng = make_engine(K, (V, F, indptr, indices, feats), B, fan, seeds=dict(train=[(seeds, labels[seeds])]))
+    for counter in range(len(seeds) // B):
+        ref = orc.run_batch(seeds, labels[seeds], counter)
+        eng.run_batch(0, counter)
+        assert_batch_equal(ref, eng.result(0))
+        assert ref["ec"][2 + len(fan)] > 20 * ref["nc"][5 + 2 * len(fan)]      # > 20 sampled edges per unique node
+    eng.close()

@@ -48,6 +48,8 @@ def parse():
                     help="where the V x F feature table lives: HBM (default) or pinned host memory read over PCIe -- the "
                          "reference's UVA configuration (GPUGraphStore.cu:315); combine with --cache unified for an HBM cache")
     ap.add_argument("--cache-frac", type=float, default=0.25, help="unified: fraction of the V feature rows cached per clique")
+    ap.add_argument("--topo-frac", type=float, default=0.0, help="unified: fraction of the V adjacency rows cached as partitioned CSR "
+                    "fragments per clique (0: topology stays replicated)")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
     ap.add_argument("--headline-only", action="store_true", help="skip the alt_schedule and graph_replay legs (clean kernel profiles)")
     ap.add_argument("--stream-priority", default="none", choices=["none", "sampler", "gather"],
@@ -441,7 +443,8 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
     D.allreduce_device_u64(K, L.GPUCache_GetEdgeAccessedMap(eng.cache, me), V, world, device=dev)
     rows = int(V * args.cache_frac) // world + 1
     mode = {1: 0, 2: 1, 4: 2, 8: 3}[world]
-    eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=0, train_step=args.presc_steps)
+    topo_rows = (int(V * args.topo_frac) // world + 1) if args.topo_frac > 0 else 0
+    eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=topo_rows, train_step=args.presc_steps)
     everyone = D.allgather_object(eng.export_shards(me), world)
     for turn in range(world):          # one importer at a time
         if turn == me:
@@ -453,7 +456,9 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
                 print(f"[rank {me}] imported {world - 1} shard(s) of {rows * F * 4 / 1e9:.1f} GB in {time.time() - t_imp:.2f} s", flush=True)
         D.barrier(world)
     return {"Kg": world, "rows_per_gpu": rows, "cached_fraction_of_V": round(rows * world / V, 4), "presc_steps": args.presc_steps,
-            "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)"}
+            "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)" if topo_rows == 0 else
+                        f"hottest {topo_rows} adjacency rows per GPU in partitioned CSR fragments (owner/row lookup fused into the sampler), rest from the replica",
+            "topo_rows_per_gpu": topo_rows}
 
 
 def unified_cache_traffic(K, L, eng, me, world, V, F, cache_info, gather_ms, dev):

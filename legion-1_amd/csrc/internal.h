@@ -111,7 +111,11 @@ struct GatherArgs {
     // chunks so that each piece can be exported over HIP IPC)
     const float* const* shard_tab;
     int32_t chunk_shift, nchunks;
+    int32_t n_tab;                            // entries of shard_tab: clique size x nchunks
     const int32_t* feat_map;                  // int32[V] global slot or -1; null = no cache
+    const float** row_ptr;                    // scratch [rows]: address of each row's source (own shard / peer shard / backing
+                                              // table / null), resolved by a lookup pass in front of the gather; null: resolve
+                                              // inside the gather (no cache)
     int32_t cache_capacity;                   // rows per GPU
     int32_t F;
     int32_t total_num_nodes;
@@ -122,6 +126,7 @@ struct GatherArgs {
     int32_t dst_rows;                         // capacity of dst in rows (<= 0: unbounded)
     int32_t* rows_seen;                       // host-mapped word: the launch leaves its actual row count here (may be null)
     int32_t rows_hint;                        // row count of an earlier launch of this kind (0: unknown)
+    bool table_on_host;                       // the backing table is pinned host memory (misses cross PCIe)
 };
 void launch_gather(hipStream_t s, const GatherArgs& a, int32_t rows_bound);
 void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_t hops, unsigned long long* access,
@@ -180,6 +185,7 @@ struct GPUMemoryPool {
     int32_t* tile_node = nullptr;
     legion::HopState* hop_state = nullptr;
     int32_t* cache_search_buffer = nullptr;
+    const float** row_ptr = nullptr;  // [num_ids] row source addresses of the running gather (cached configurations)
     int32_t* agg_src_ids = nullptr;
     int8_t* tmp_part_ind = nullptr;
     int32_t* tmp_part_off = nullptr;

@@ -554,9 +554,57 @@ struct GatherKArgs {
     GatherArgs g;
     FastDiv div_c;   // / chunks-per-row
     FastDiv div_cap; // / cache_capacity
+    int32_t n_tab;   // entries of g.shard_tab (clique size x chunks per shard)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+
+// FindFeat + source selection for the rows of one gather launch (GPUCache.cu:387-400, Kernels.cu:672-691): one thread
+// per ROW resolves id -> cache slot -> (clique GPU, chunk, row) -> address, or the backing-table row on a miss.  The
+// gather then starts every row with one coalesced 8-byte load; done inside the gather, the map probe and the
+// chunk-table load sit on the critical path of every 16-byte chunk (profiles/r01_gather_sweep.md).
+__global__ __launch_bounds__(kBlock) void k_row_ptrs(GatherKArgs a)
+{
+    constexpr int U = 4; // rows per thread and step: U independent map probes in flight
+    constexpr int kTabMax = 1024;
+    __shared__ const float* s_tab[kTabMax]; // the chunk-pointer table (Kg x nchunks entries): every row reads it
+    const GatherArgs& g = a.g;
+    const int32_t n_tab = g.shard_tab ? a.n_tab : 0;
+    const bool tab_in_lds = n_tab <= kTabMax;
+    if (tab_in_lds) {
+        for (int32_t i = threadIdx.x; i < n_tab; i += blockDim.x) s_tab[i] = g.shard_tab[i];
+        __syncthreads();
+    }
+    const int32_t off = g.off_idx < 0 ? 0 : g.nc[g.off_idx];
+    const int32_t rows = g.nc[g.size_idx];
+    const int32_t stride = gridDim.x * blockDim.x;
+    for (int32_t r0 = threadIdx.x + blockDim.x * blockIdx.x; r0 < rows; r0 += stride * U) {
+        int32_t id[U], gidx[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t r = r0 + u * stride;
+            id[u] = r < rows ? g.sampled_ids[off + r] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) gidx[u] = (id[u] >= 0 && g.feat_map) ? g.feat_map[id[u]] : -1;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t r = r0 + u * stride;
+            if (r >= rows) continue;
+            const float* src = nullptr;
+            if (gidx[u] >= 0) {
+                const uint32_t didx = fdiv((uint32_t)gidx[u], a.div_cap);
+                const uint32_t fidx = (uint32_t)gidx[u] - didx * (uint32_t)g.cache_capacity;
+                const uint32_t t = didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift);
+                const float* chunk = tab_in_lds ? s_tab[t] : g.shard_tab[t];
+                src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * g.F;
+            } else if (id[u] >= 0 && g.table) {
+                src = g.table + (int64_t)(id[u] % g.total_num_nodes) * g.F;
+            }
+            g.row_ptr[r] = src;
+        }
+    }
+}
 
 template <typename VT, int UNROLL, int NT>
 __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
@@ -582,18 +630,14 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
                 const uint32_t r = fdiv((uint32_t)q, a.div_c); // rows*C < 2^31 is checked by the launcher
                 const uint32_t ch = (uint32_t)q - r * (uint32_t)C;
                 if (g.dst_rows > 0 && off + (int32_t)r >= g.dst_rows) continue; // never write past the buffer
-                const int32_t id = g.sampled_ids[off + (int32_t)r];
-                int32_t gidx = -1;
-                if (g.feat_map && id >= 0) gidx = g.feat_map[id]; // FindFeat fused
-                if (gidx >= 0) {
-                    const uint32_t didx = fdiv((uint32_t)gidx, a.div_cap);
-                    const uint32_t fidx = (uint32_t)gidx - didx * (uint32_t)g.cache_capacity;
-                    const float* chunk = g.shard_tab[didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
-                    src[u] = reinterpret_cast<const VT*>(chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * g.F) + ch;
-                } else if (id >= 0) {
-                    src[u] = reinterpret_cast<const VT*>(g.table + (int64_t)(id % g.total_num_nodes) * g.F) + ch;
-                }
                 dsti[u] = ((int64_t)(off + (int32_t)r) * g.F) / VEC + ch;
+                if (g.row_ptr) { // resolved by k_row_ptrs
+                    const float* p = g.row_ptr[r];
+                    if (p) src[u] = reinterpret_cast<const VT*>(p) + ch;
+                    continue;
+                }
+                const int32_t id = g.sampled_ids[off + (int32_t)r]; // no cache: the backing table row (Kernels.cu:689)
+                if (id >= 0) src[u] = reinterpret_cast<const VT*>(g.table + (int64_t)(id % g.total_num_nodes) * g.F) + ch;
             }
         }
 #pragma unroll
@@ -863,6 +907,7 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     const int C = vec4 ? g.F / 4 : g.F;
     if ((int64_t)rows_bound * C >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);
+    a.n_tab = g.n_tab;
     // Tuned on MI355X (profiles/r01_gather_sweep.md): non-temporal loads and stores (rows are read once and
     // written once: keep them out of L2/MALL).
     // One 16-byte chunk per lane and iteration.  Best measured with 2-3 iterations per lane: fewer workgroups
@@ -870,9 +915,14 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // bound is typically filled 15-60 %, so the grid is sized from the row count an earlier launch of this kind
     // reported (rows_seen, no host round trip), + 25 %; without a report: the bound, at most 512 workgroups per CU.
     int grid;
+    if (g.row_ptr) {
+        const int64_t est_rows = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
+        k_row_ptrs<<<grid_for(est_rows, kBlock * 4, 64), kBlock, 0, s>>>(a);
+        HIP_CHECK_LAST();
+    }
     if (g.rows_hint > 0) {
         const int64_t est = std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024);
-        grid = grid_for(est * C, kBlock * 3, 8192);
+        grid = grid_for(est * C, kBlock * (g.table_on_host ? 1 : 3), 8192); // rows over PCIe: latency-bound, maximise lanes in flight
     } else {
         grid = grid_for((int64_t)rows_bound * C, kBlock, 512);
     }

@@ -153,8 +153,10 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return; }
     GatherArgs g;
     g.table = (dev_id >= 0 && dev_id < noder->partition_count && noder->replica_attrs[dev_id]) ? noder->replica_attrs[dev_id] : noder->float_attrs;
-    g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1;
+    g.table_on_host = g.table == noder->float_attrs && noder->features_location != LEGION_LOC_DEVICE;
+    g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1; g.n_tab = 0;
     g.feat_map = nullptr;
+    g.row_ptr = nullptr;
     g.cache_capacity = 1;
     g.F = F;
     g.total_num_nodes = noder->total_num_nodes;
@@ -178,6 +180,8 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
         g.shard_tab = cache->d_shard_tab[dev_id]; // d_float_feature_cache_ptr_, GPUCache.cu:788-816
         g.chunk_shift = cache->chunk_shift[Ki];
         g.nchunks = cache->nchunks[Ki];
+        g.n_tab = cache->Kg * cache->nchunks[Ki];
+        g.row_ptr = p->row_ptr; // FindFeat + source selection as their own pass over the rows (k_row_ptrs)
     }
     if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return; }
     launch_gather((hipStream_t)strm_hdl, g, rows_bound);

@@ -111,7 +111,6 @@ struct GatherArgs {
     // chunks so that each piece can be exported over HIP IPC)
     const float* const* shard_tab;
     int32_t chunk_shift, nchunks;
-    int32_t n_tab;                            // entries of shard_tab: clique size x nchunks
     const int32_t* feat_map;                  // int32[V] global slot or -1; null = no cache
     const float** row_ptr;                    // scratch [rows]: address of each row's source (own shard / peer shard / backing
                                               // table / null), resolved by a lookup pass in front of the gather; null: resolve

@@ -554,7 +554,6 @@ struct GatherKArgs {
     GatherArgs g;
     FastDiv div_c;   // / chunks-per-row
     FastDiv div_cap; // / cache_capacity
-    int32_t n_tab;   // entries of g.shard_tab (clique size x chunks per shard)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -566,15 +565,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(kBlock) void k_row_ptrs(GatherKArgs a)
 {
     constexpr int U = 4; // rows per thread and step: U independent map probes in flight
-    constexpr int kTabMax = 1024;
-    __shared__ const float* s_tab[kTabMax]; // the chunk-pointer table (Kg x nchunks entries): every row reads it
     const GatherArgs& g = a.g;
-    const int32_t n_tab = g.shard_tab ? a.n_tab : 0;
-    const bool tab_in_lds = n_tab <= kTabMax;
-    if (tab_in_lds) {
-        for (int32_t i = threadIdx.x; i < n_tab; i += blockDim.x) s_tab[i] = g.shard_tab[i];
-        __syncthreads();
-    }
     const int32_t off = g.off_idx < 0 ? 0 : g.nc[g.off_idx];
     const int32_t rows = g.nc[g.size_idx];
     const int32_t stride = gridDim.x * blockDim.x;
@@ -595,8 +586,7 @@ __global__ __launch_bounds__(kBlock) void k_row_ptrs(GatherKArgs a)
             if (gidx[u] >= 0) {
                 const uint32_t didx = fdiv((uint32_t)gidx[u], a.div_cap);
                 const uint32_t fidx = (uint32_t)gidx[u] - didx * (uint32_t)g.cache_capacity;
-                const uint32_t t = didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift);
-                const float* chunk = tab_in_lds ? s_tab[t] : g.shard_tab[t];
+                const float* chunk = g.shard_tab[didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
                 src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * g.F;
             } else if (id[u] >= 0 && g.table) {
                 src = g.table + (int64_t)(id[u] % g.total_num_nodes) * g.F;
@@ -907,7 +897,6 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     const int C = vec4 ? g.F / 4 : g.F;
     if ((int64_t)rows_bound * C >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);
-    a.n_tab = g.n_tab;
     // Tuned on MI355X (profiles/r01_gather_sweep.md): non-temporal loads and stores (rows are read once and
     // written once: keep them out of L2/MALL).
     // One 16-byte chunk per lane and iteration.  Best measured with 2-3 iterations per lane: fewer workgroups

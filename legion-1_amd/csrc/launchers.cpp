@@ -154,7 +154,7 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     GatherArgs g;
     g.table = (dev_id >= 0 && dev_id < noder->partition_count && noder->replica_attrs[dev_id]) ? noder->replica_attrs[dev_id] : noder->float_attrs;
     g.table_on_host = g.table == noder->float_attrs && noder->features_location != LEGION_LOC_DEVICE;
-    g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1; g.n_tab = 0;
+    g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1;
     g.feat_map = nullptr;
     g.row_ptr = nullptr;
     g.cache_capacity = 1;
@@ -180,7 +180,6 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
         g.shard_tab = cache->d_shard_tab[dev_id]; // d_float_feature_cache_ptr_, GPUCache.cu:788-816
         g.chunk_shift = cache->chunk_shift[Ki];
         g.nchunks = cache->nchunks[Ki];
-        g.n_tab = cache->Kg * cache->nchunks[Ki];
         g.row_ptr = p->row_ptr; // FindFeat + source selection as their own pass over the rows (k_row_ptrs)
     }
     if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return; }

@@ -51,13 +51,14 @@ def _worker(rank, world, port, q):
         seeds = dict(train=[(p, ds.labels[p]) for p in parts])
         eng = K.Engine(ds.indptr, ds.indices, ds.features, V, F, seeds, B, fan, G=world, local_devs=[rank], train_step=steps)
         eng.alloc_features()
-        assert L.legion_is_remote_device(1 - rank) == 1 and L.legion_is_remote_device(rank) == 0
+        peers = [g for g in range(world) if g != rank]
+        assert all(L.legion_is_remote_device(g) == 1 for g in peers) and L.legion_is_remote_device(rank) == 0
         # pre-sampling epoch on the own partition, then the clique-wide hotness sum as a collective
         for it in range(steps):
             eng.run_batch(rank, it, is_presc=True)
         D.allreduce_device_u64(K, L.GPUCache_GetNodeAccessedMap(eng.cache, rank), V, world)
         D.allreduce_device_u64(K, L.GPUCache_GetEdgeAccessedMap(eng.cache, rank), V, world)
-        eng.build_cache(cache_agg_mode=1, node_capacity=cap, edge_capacity=cap, train_step=steps)
+        eng.build_cache(cache_agg_mode={2: 1, 4: 2}[world], node_capacity=cap, edge_capacity=cap, train_step=steps)
         # oracle: hotness of BOTH partitions -> same ranking on every rank
         orcs = [O.OracleRunner(ds.indptr, ds.indices, ds.features, V, F, B, fan, partition_count=world) for _ in range(world)]
         for g in range(world):
@@ -75,22 +76,23 @@ def _worker(rank, world, port, q):
         for g in range(world):
             if g != rank:
                 eng.import_shards(g, everyone[g])
-        assert L.GPUCache_Float_Feature_Cache(eng.cache, 1 - rank)
-        assert L.GPUGraphStorage_GetFragmentIndex(eng.graph, rank, 1 - rank)                       # peer fragment visible from here
-        assert L.GPUGraphStorage_FragmentChunkCount(eng.graph, 1 - rank, 1) == len(everyone[1 - rank][2])
-        assert L.GPUGraphStorage_FragmentEdges(eng.graph, 1 - rank) == everyone[1 - rank][3][1]
+        for g in peers:
+            assert L.GPUCache_Float_Feature_Cache(eng.cache, g)
+            assert L.GPUGraphStorage_GetFragmentIndex(eng.graph, rank, g)                          # peer fragment visible from here
+            assert L.GPUGraphStorage_FragmentChunkCount(eng.graph, g, 1) == len(everyone[g][2])
+            assert L.GPUGraphStorage_FragmentEdges(eng.graph, g) == everyone[g][3][1]
         # steady state through the unified cache: own shard, peer shard (IPC) and backing-table misses
         me = orcs[rank]
         me.set_feature_cache(QF, cap, world)
         me.set_topo_cache(QT, cap, world, 0)
         peer_rows = 0
-        for it in range(3):
+        for it in range(min(3, (len(parts[rank]) + B - 1) // B)):       # never past the end of the seed shard
             ref = me.run_batch(parts[rank], ds.labels[parts[rank]], it)
             eng.run_batch(rank, it)
             got = eng.result(rank)
             assert_batch_equal(ref, got)
             slot = me.node_map[got["ids"]]
-            peer_rows += int(((slot >= 0) & (slot // cap == 1 - rank)).sum())
+            peer_rows += int(((slot >= 0) & (slot // cap != rank)).sum())
             assert ((slot >= 0) & (slot // cap == rank)).any() and (slot < 0).any()
         assert peer_rows > 0
         dist.barrier()        # nobody unmaps a shard while the peer may still read it
@@ -103,8 +105,9 @@ def _worker(rank, world, port, q):
         q.put((rank, "fail", traceback.format_exc() + repr(ex)))
 
 
-def test_two_process_clique_unified_cache_over_ipc():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4])
+def test_process_per_gpu_clique_unified_cache_over_ipc(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]

@@ -6,7 +6,7 @@
 //   S3 kernel_random_sampler_2        Kernels.cu:342-448    -> k_sample + k_mark + k_write
 //   S3' kernel_pre_sampler_optimized  Kernels.cu:468-564    -> k_sample<PRESC>
 //   S4 construct_graph                Kernels.cu:450-463    -> k_write (dst side) + k_resolve (src side)
-//   S5 zero_copy_with_aggregated_cache Kernels.cu:662-702   -> k_gather
+//   S5 zero_copy_with_aggregated_cache Kernels.cu:662-702   -> k_gather (+ k_row_ptrs in front of a cached gather)
 //   S6 FindFeat/FindTopo (BGHT find)  GPUCache.cu:387-461   -> direct-mapped int32/int8[V] tables
 //   S7 ClearPosMap / HotnessMeasure   Kernels.cu:750-756, GPUCache.cu:227-235
 //
@@ -15,15 +15,17 @@
 //    canonical schedule (serial, slot-index ascending) deterministically: a hop is
 //      k_sample : every slot draws its neighbour (same Thrust minstd arithmetic), parks it in
 //                 cand[idx] and claims the node with atomicMin(pos[dst], PROVISIONAL|idx), so the
-//                 LOWEST slot that touches a new node wins -- exactly the serial order; a neighbour
-//                 whose final position is already in the table is recorded in aux[idx];
-//      k_mark   : the winner of each new node is flagged (its claim survived), a loser records the
-//                 winning slot; per-tile edge / new-node counts are now known;
+//                 LOWEST slot that touches a new node wins -- exactly the serial order.  Slot state
+//                 aux[idx]: -1 claim pending / won, >= 0 the neighbour's known final position,
+//                 <= -2 lost to slot -2-x.  Repeated draws of a row are settled in-wave; a claim that
+//                 replaces a larger slot's claim writes that slot's state ("you lost to me");
+//      k_mark   : streaming count of the states still at -1 = new nodes per tile (no table probe);
 //      k_write  : every workgroup sums the tile counts in front of its tile (no scan launch), then
 //                 ordered compaction (wave ballot + popcount prefix, one LDS exchange per tile)
 //                 appends edges / new nodes at their canonical positions and the COO offsets; the
 //                 workgroup of the last tile applies update_counter (S2);
-//      k_resolve: src-side COO offsets of the edges that lost their claim, from the winner's slot.
+//      k_resolve: src-side COO offsets of the edges that lost their claim, following loser -> winner
+//                 through the slot states; prepares the next hop's states (-1).
 //  * One u64[V] "position table" replaces accessed_map (bitmap) + position_map.  Entry =
 //    (epoch << 32) | value, epoch = 0xFFFFFFFF - batch serial, so entries of older batches compare
 //    GREATER than anything of the running batch: they are stale without ever being cleared (no

@@ -645,3 +645,26 @@ def test_heavy_duplicate_contention(K, oracle, V, B, fan):
         assert_batch_equal(ref, eng.result(0))
         assert ref["ec"][2 + len(fan)] > 20 * ref["nc"][5 + 2 * len(fan)]      # > 20 sampled edges per unique node
     eng.close()
+
+
+def test_fanout_other_than_the_pool_was_prepared_for(K, oracle, small_ds):
+    """GPU_Random_Sampling takes the fan-out per call (Operator.cu:48 passes neighbor_count): a hop launched with a
+    count the previous launch did not prepare the slot states for falls back to an explicit fill (k_fill_aux)."""
+    ds = small_ds
+    B, pool_fan, fan = 200, [10, 5], [7, 3]
+    L = K.lib()
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, pool_fan)
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    pool = eng.pools[0]
+    for it in range(3):
+        L.GPUMemoryPool_SetCurrentPipe(pool, 0)
+        L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        L.batch_generator_kernel(None, eng.noder, eng.cache, pool, B, it, 0, 0, K.TRAINMODE)
+        for h in range(2):
+            L.GPU_Random_Sampling(None, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
+        L.get_feature_kernel_all(None, eng.cache, eng.noder, pool, 0, 1)
+        L.d_stream_sync(None)
+        K.check()
+        assert_batch_equal(orc.run_batch(ds.train, ds.labels[ds.train], it), eng.result(0))
+    eng.close()

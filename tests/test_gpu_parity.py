@@ -668,3 +668,27 @@ def test_fanout_other_than_the_pool_was_prepared_for(K, oracle, small_ds):
         K.check()
         assert_batch_equal(orc.run_batch(ds.train, ds.labels[ds.train], it), eng.result(0))
     eng.close()
+
+
+def test_repeatability_under_contention(K, oracle):
+    """The same heavily contended batch over and over ($LEGION_SOAK_N times, default 30): the result never depends on
+    which slot reached the table first -- every repetition is bit-identical to the oracle's canonical schedule."""
+    import os
+    V, B, fan, F = 5000, 1000, [25, 10, 5], 4
+    rng = np.random.RandomState(7)
+    deg = rng.randint(10, 80, size=V)
+    indptr = np.zeros(V + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    hot = rng.randint(0, V, size=50)
+    indices = np.where(rng.rand(int(indptr[-1])) < 0.6, rng.choice(hot, size=int(indptr[-1])), rng.randint(0, V, size=int(indptr[-1]))).astype(np.int32)
+    feats = rng.rand(V, F).astype(np.float32)
+    labels = rng.randint(0, 5, size=V).astype(np.int32)
+    seeds = rng.permutation(V)[:2 * B].astype(np.int32)
+    orc = oracle.OracleRunner(indptr, indices, feats, V, F, B, fan)
+    refs = [orc.run_batch(seeds, labels[seeds], c) for c in (0, 1)]
+    eng = make_engine(K, (V, F, indptr, indices, feats), B, fan, seeds=dict(train=[(seeds, labels[seeds])]))
+    for rep in range(int(os.environ.get("LEGION_SOAK_N", "30"))):
+        c = rep & 1
+        eng.run_batch(0, c, per_level=False)
+        assert_batch_equal(refs[c], eng.result(0))
+    eng.close()

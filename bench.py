@@ -341,13 +341,15 @@ def main():
             gather_launch_bytes = gather_bytes
         ach = float(gather_launch_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))   # newest round last
+        pmc = pmcs[-1] if pmcs else ""
         if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and not unified and not intra and args.table == "device" and os.path.exists(pmc):
             # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
             # command (counters cannot be read from inside the process); gfx950 FETCH_SIZE x2 correction applied
             with open(pmc) as f:
                 traffic = json.load(f)["k_gather"]["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01_pmc_hbm_traffic.json"
+            traffic_src = "profiles/" + os.path.basename(pmc)
         roofline = dict(bound="hbm", kernel="k_gather<float4, non-temporal>", achieved=round(ach, 1),
                         peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
                         traffic_source=traffic_src, avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),

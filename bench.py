@@ -3,36 +3,44 @@
 synthetic graph of the ogbn-papers100M shape (BASELINE.json metric), one process per GPU.
 
   python bench.py --gpus 1 --steps 50 --warmup 5
+  python bench.py --gpus N ...          # spawns N ranks itself (parent never touches the GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one mini-batch (B seeds, H-hop sampling, COO construction, gather of every unique
 node's feature row) with CSR and features already resident in HBM.  Each rank owns the seeds
 `tid % N == rank` (GPUGraphStore.cu:332-346) and a full replica of the graph (Kg = 1), so there is
-no data-path collective: scaling is weak.  Rank 0 prints ONE JSON line.
+no data-path collective: scaling is weak.  With N > 1 the same processes then run the reference's
+unified feature cache (Kg = N: rank-t hot row on GPU t % N, peer shards read in-kernel over xGMI;
+GPUCache.cu:88-108,593-607) and report it inside the same line.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (/opt/skills/guides/MI355X_MICROARCH.md)
+XGMI_PEAK_GBPS = 7 * 153.0  # 7 point-to-point links x ~153 GB/s per GPU
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="papers100M", choices=["products", "papers100M", "uk-union"])
+    ap.add_argument("--task", default="node", choices=["node", "lp"],
+                    help="node: node-classification seeds (the training set).  lp: link-prediction seed batches laid out as "
+                         "[src | pos | neg] thirds (lp_sage.py:87-90), generated on the GPU per rank (triples split by src %% N)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink V and seed sets (debug only)")
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10,5")
@@ -42,8 +50,11 @@ def parse():
                          "the rows of level l are gathered on a second stream while hop l+1 is sampled; the last level runs alone.  "
                          "overlap: whole-batch gather of batch i on a second stream while batch i+1 is sampled (depth-2 pipes)")
     ap.add_argument("--cache", default="replicated", choices=["replicated", "unified"],
-                    help="replicated: every GPU holds all features (Kg=1).  unified: the clique-wide hotness-partitioned "
-                         "feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
+                    help="headline leg.  replicated: every GPU holds all features (Kg=1).  unified: the clique-wide "
+                         "hotness-partitioned feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
+    ap.add_argument("--no-unified-leg", action="store_true", help="N > 1: skip the unified-cache leg that follows the replicated headline")
+    ap.add_argument("--unified-timeout", type=float, default=420.0,
+                    help="N > 1: seconds the unified-cache leg may take before the headline line is printed without it")
     ap.add_argument("--table", default="device", choices=["device", "host"],
                     help="where the V x F feature table lives: HBM (default) or pinned host memory read over PCIe -- the "
                          "reference's UVA configuration (GPUGraphStore.cu:315); combine with --cache unified for an HBM cache")
@@ -51,6 +62,11 @@ def parse():
     ap.add_argument("--topo-frac", type=float, default=0.0, help="unified: fraction of the V adjacency rows cached as partitioned CSR "
                     "fragments per clique (0: topology stays replicated)")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
+    ap.add_argument("--min-time", type=float, default=0.5,
+                    help="the K-step timed window is repeated until this many seconds are covered; ms_per_step is the median window")
+    ap.add_argument("--max-reps", type=int, default=60)
+    ap.add_argument("--skew", type=int, default=205, help="synthetic neighbours: n/256 of them drawn from the Zipf-like skew "
+                    "(205 = the spec'd 80 %%; 0 = uniform neighbours, the Infinity-Cache control run)")
     ap.add_argument("--headline-only", action="store_true", help="skip the alt_schedule and graph_replay legs (clean kernel profiles)")
     ap.add_argument("--stream-priority", default="none", choices=["none", "sampler", "gather"],
                     help="overlap schedule: which of the two streams gets the high stream priority (the other the low one)")
@@ -60,11 +76,80 @@ def parse():
                     "i %% 8 < S (mod) or (i // 32) %% 8 < S (block)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
-    return ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the parent gives up on its ranks")
+    return ap.parse_args(argv)
 
 
-def build_graph_on_gpu(K, spec, dev):
+# ======================================================================================================
+# self-launch: `python bench.py --gpus N` without torchrun.  The parent never imports torch and never
+# touches the GPU; it starts N fresh children (never exec, never a restart of a process that has
+# initialised the GPU), waits for them and fails if any of them fails.
+# ======================================================================================================
+def launch_plan(args, environ):
+    """What main() does with this (--gpus, environment): 'worker' (run here), 'spawn' (start N ranks) or an error text."""
+    ws = environ.get("WORLD_SIZE")
+    if ws is None:
+        if args.gpus < 1:
+            return "error: --gpus must be >= 1"
+        return "spawn" if args.gpus > 1 else "worker"
+    if int(ws) != args.gpus:
+        return f"error: --gpus {args.gpus} but WORLD_SIZE={ws}: refusing to run a different number of ranks than asked for"
+    return "worker"
+
+
+def child_env(environ, rank, world, port):
+    env = dict(environ)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               LEGION_BENCH_SPAWNED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only mode this pool's driver supports
+    return env
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0):
+    port = free_port()
+    procs = [popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=child_env(os.environ, r, args.gpus, port))
+             for r in range(args.gpus)]
+    deadline = time.time() + args.launch_timeout
+    first_bad = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [c for c in codes if c not in (None, 0)]
+        now = time.time()
+        if bad and first_bad is None:
+            first_bad = now                       # a dead rank leaves the others in a collective: give them a moment, then stop them
+        if (first_bad is not None and now - first_bad > grace_s) or now > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                      # exactly the PIDs started above
+            for p in procs:
+                p.wait()
+            if now > deadline and first_bad is None:
+                print(f"bench.py: ranks did not finish within {args.launch_timeout:.0f} s", file=sys.stderr)
+                return 124
+            break
+        time.sleep(poll_s)
+    codes = [p.returncode for p in procs]
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return next(c for c in codes if c) or 1
+    return 0
+
+
+# ======================================================================================================
+# worker: one rank
+# ======================================================================================================
+def build_graph_on_gpu(K, spec, dev, skew=205):
     """Synthetic dataset generated on the GPU by csrc/synth.hip (spec: legion-1_amd/synth.py)."""
+    import torch
     L = K.lib()
     V, F = spec.V, spec.F
     ladder = np.ascontiguousarray(spec.ladder, dtype=np.int32)
@@ -75,7 +160,7 @@ def build_graph_on_gpu(K, spec, dev):
     del deg
     E = int(indptr[-1].item())
     indices = torch.empty(E, dtype=torch.int32, device=dev)
-    L.legion_synth_neighbors(None, indices.data_ptr(), 0, E, V, spec.M, spec.C)
+    L.legion_synth_neighbors_skew(None, indices.data_ptr(), 0, E, V, spec.M, spec.C, skew)
     feats = torch.empty((V, F), dtype=torch.float32, device=dev)
     L.legion_synth_features(None, feats.data_ptr(), 0, V, F)
     torch.cuda.synchronize()
@@ -83,23 +168,33 @@ def build_graph_on_gpu(K, spec, dev):
     return indptr, indices, feats, E
 
 
-def main():
-    args = parse()
+class Ctx:
+    """Everything the legs share: the rank's device, the synthetic graph and this rank's seed list."""
+
+
+def worker(args):
+    import torch
     if os.environ.get("LEGION_BENCH_WATCHDOG"):  # debugging aid: dump all Python stacks and exit if stuck
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["LEGION_BENCH_WATCHDOG"]), exit=True)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    c = Ctx()
+    c.args = args
+    c.rank = rank = int(os.environ.get("RANK", "0"))
+    c.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
     # Rehearsal on a one-GPU box: LEGION_BENCH_FORCE_DEVICE=0 puts every rank on that device and uses gloo
     # (RCCL refuses two ranks on one GPU).  Never set on a real multi-GPU run.
     forced = os.environ.get("LEGION_BENCH_FORCE_DEVICE")
+    c.shared_device = forced is not None and world > 1
     if forced is not None:
         local_rank = int(forced)
+    n_vis = torch.cuda.device_count()
+    if local_rank >= n_vis:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {n_vis} GPU(s) are visible "
+                         f"(--gpus {args.gpus}): refusing to run on fewer GPUs than asked for")
+    c.local_rank = local_rank
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    c.dev = dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -109,54 +204,146 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import legion1_amd.capi as K
+    import legion1_amd.dist as D
     import legion1_amd.synth as S
-    L = K.lib()
-    unified = args.cache == "unified"
-    G = world if unified else 1          # logical GPUs of the clique this process knows about
-    me = rank if unified else 0          # the one this process drives
-    for g in range(G):
-        L.legion_set_device_map(g, local_rank)
-    L.SetGPUDevice(me)
-
-    fan = [int(x) for x in args.fanout.split(",")]
-    H = len(fan)
-    B = args.batch
-    spec = S.spec_for(args.workload, scale=args.scale)
+    c.K, c.D, c.S = K, D, S
+    c.L = L = K.lib()
+    c.fan = fan = [int(x) for x in args.fanout.split(",")]
+    c.H = len(fan)
+    c.B = B = args.batch
+    c.spec = spec = S.spec_for(args.workload, scale=args.scale)
     V, F = spec.V, spec.F
+    L.legion_set_device_map(0, local_rank)
+    L.SetGPUDevice(0)
     t0 = time.time()
-    indptr, indices, feats, E = build_graph_on_gpu(K, spec, dev)
-    feat_ptr, feat_loc, host_table = feats.data_ptr(), K.LOC_DEVICE, None
+    c.indptr, c.indices, c.feats, c.E = build_graph_on_gpu(K, spec, dev, args.skew)
+    c.feat_ptr, c.feat_loc, c.host_table = c.feats.data_ptr(), K.LOC_DEVICE, None
     if args.table == "host":   # move the table to pinned, device-mapped host memory; misses then cross PCIe
         nbytes = V * F * 4
-        host_table = L.host_alloc_space64(nbytes)
-        L.d_copy_d_2_h(host_table, feats.data_ptr(), nbytes)
+        c.host_table = L.host_alloc_space64(nbytes)
+        L.d_copy_d_2_h(c.host_table, c.feats.data_ptr(), nbytes)
         K.check()
-        del feats
-        feats = None
+        c.feats = None
         torch.cuda.empty_cache()
-        feat_ptr, feat_loc = host_table, K.LOC_HOST_PINNED
-    # seeds of this rank: train ids with tid % world == rank, labels from the generator
+        c.feat_ptr, c.feat_loc = c.host_table, K.LOC_HOST_PINNED
+    make_seeds(c)
+    c.gen_s = time.time() - t0
+
+    head = run_leg(c, unified=(args.cache == "unified"), headline=True)
+
+    line = None
+    if rank == 0:
+        line = headline_line(c, head)
+    second = None
+    if world > 1 and args.cache == "replicated" and not args.no_unified_leg and args.table == "device":
+        second = guarded_unified_leg(c, line)
+    if line is not None and second is not None:
+        line["unified_cache"] = second
+
+    # measured streaming-copy rate of this box (float4 copy kernel sized like the gather, read + write bytes)
+    if rank == 0 and line.get("roofline") is not None:
+        line["roofline"]["measured_copy_GBps"] = measure_copy(c)
+    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
+        feats = c.feats
+        if c.host_table is not None:   # the table already is host memory: view it, no copy
+            import ctypes
+            feats = np.ctypeslib.as_array(ctypes.cast(c.host_table, ctypes.POINTER(ctypes.c_float)), shape=(V, F))
+        try:
+            line["cpu_baseline"] = run_cpu_baseline(args, spec, c.indptr, c.indices, feats, c.mine, c.my_labels, B, fan, c.steps_avail)
+        except Exception as ex:   # noqa: BLE001 -- reported baseline only: never lose the headline line over it
+            line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def make_seeds(c):
+    """This rank's seed list + labels on the device.  node: train ids with tid % world == rank
+    (GPUGraphStore.cu:332-346).  lp: [src | pos | neg] batches over the triples whose src % world == rank."""
+    import torch
+    args, L, spec, dev = c.args, c.L, c.spec, c.dev
+    V = spec.V
     all_train = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
     L.legion_synth_seed_ids(None, all_train.data_ptr(), 0, spec.n_train, V, spec.M2, spec.C2, 1, 0)
     torch.cuda.synchronize()
-    import legion1_amd.dist as D
-    mine = D.shard_seeds(all_train, rank, world).contiguous()
-    del all_train
+    mask = (all_train % c.world) == c.rank
+    mine = all_train[mask].contiguous()              # == dist.shard_seeds(all_train, rank, world)
+    if args.task == "lp":
+        if c.B % 3:
+            raise SystemExit("--task lp needs a batch size divisible by 3 ([src | pos | neg] thirds, lp_sage.py:87-90)")
+        k = c.B // 3
+        # one triple per training id; triple t of the global list belongs to rank src_t % N and keeps its global
+        # number for the pos / neg draws, so the lists of all ranks together are the 1-rank list re-dealt
+        triple_no = torch.nonzero(mask).reshape(-1).contiguous()
+        n_tr = int(mine.numel())
+        seeds = torch.empty((n_tr + k - 1) // k * c.B, dtype=torch.int32, device=dev)
+        L.legion_synth_lp_seeds(None, seeds.data_ptr(), mine.data_ptr(), triple_no.data_ptr(), n_tr, c.B, c.indptr.data_ptr(),
+                                c.indices.data_ptr(), V, 1)
+        torch.cuda.synchronize()
+        c.K.check()
+        mine = seeds
+        del triple_no
+    del all_train, mask
     labels_all = torch.empty(V, dtype=torch.int32, device=dev)
     L.legion_synth_labels(None, labels_all.data_ptr(), 0, V, spec.classes)
     torch.cuda.synchronize()
-    my_labels = labels_all[mine.long()].contiguous()
+    c.my_labels = labels_all[mine.long()].contiguous()
     del labels_all
-    n_mine = int(mine.numel())
-    gen_s = time.time() - t0
+    c.mine = mine
+    c.n_mine = int(mine.numel())
+    c.steps_avail = max(1, (c.n_mine - 1) // c.B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
 
+
+def guarded_unified_leg(c, line):
+    """The unified-cache leg must never cost the headline: a failure is reported inside the line, and if the leg
+    does not finish in time (an IPC import that never returns, profiles/r01_unified_ipc_notes.md) rank 0 prints
+    the headline without it and every rank leaves."""
+    def fire():
+        if c.rank == 0:
+            line["unified_cache"] = {"error": f"did not finish within {c.args.unified_timeout:.0f} s"}
+            print(json.dumps(line), flush=True)
+        os._exit(0 if c.rank == 0 else 3)
+    timer = threading.Timer(c.args.unified_timeout, fire)
+    timer.daemon = True
+    timer.start()
+    try:
+        ok, res = True, None
+        try:
+            leg = run_leg(c, unified=True, headline=False)
+            res = unified_summary(c, leg)
+        except Exception as ex:  # noqa: BLE001
+            ok, res = False, {"error": repr(ex)[:300]}
+        # every rank must agree that the leg worked before its numbers are believed
+        flags = c.D.allgather_object(ok, c.world)
+        if not all(flags) and ok:
+            res = {"error": "failed on rank(s) %s" % [i for i, f in enumerate(flags) if not f]}
+        return res
+    finally:
+        timer.cancel()
+
+
+def run_leg(c, unified, headline):
+    """W warm-up steps, then R windows of exactly K timed steps (barrier + synchronize on both sides of every
+    window, max over ranks per window, median over windows).  Returns the raw numbers of the leg."""
+    import torch
+    args, K, D, L = c.args, c.K, c.D, c.L
+    rank, world, dev = c.rank, c.world, c.dev
+    V, F, B, fan, H = c.spec.V, c.spec.F, c.B, c.fan, c.H
+    G = world if unified else 1          # logical GPUs of the clique this process knows about
+    me = rank if unified else 0          # the one this process drives
+    for g in range(G):
+        L.legion_set_device_map(g, c.local_rank)
+    L.SetGPUDevice(me)
+    n_mine = c.n_mine
     empty = (np.zeros(0, np.int32), np.zeros(0, np.int32))
-    seeds = dict(train=[((mine.data_ptr(), n_mine), (my_labels.data_ptr(), n_mine)) if g == me else empty for g in range(G)])
-    overlap = args.pipeline == "overlap" and args.gather == "all"
-    intra = args.pipeline == "intra"
+    seeds = dict(train=[((c.mine.data_ptr(), n_mine), (c.my_labels.data_ptr(), n_mine)) if g == me else empty for g in range(G)])
+    overlap = args.pipeline == "overlap" and args.gather == "all" and headline
+    intra = args.pipeline == "intra" and headline
     depth = 2      # the reference's PIPELINE_DEPTH; the serial schedule only uses pipe 0
-    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feat_ptr, V, F, seeds, B, fan, G=G,
-                   csr_location=K.LOC_DEVICE, features_location=feat_loc, E=E, pipeline_depth=depth,
+    eng = K.Engine(c.indptr.data_ptr(), c.indices.data_ptr(), c.feat_ptr, V, F, seeds, B, fan, G=G,
+                   csr_location=K.LOC_DEVICE, features_location=c.feat_loc, E=c.E, pipeline_depth=depth,
                    local_devs=[me], train_step=max(1, args.presc_steps))
     eng.alloc_features()
     cache_info = None
@@ -164,7 +351,7 @@ def main():
         cache_info = build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev)
     else:
         L.GPUCache_SetPreSc(eng.cache, 0)  # steady state: no pre-sampling epoch in the all-resident configuration
-    if args.cu_split > 0:
+    if args.cu_split > 0 and headline:
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         words = (n_cu + 31) // 32
         owner = [(i % 8 if args.cu_pattern == "mod" else (i // 32) % 8) < args.cu_split for i in range(words * 32)]
@@ -172,16 +359,16 @@ def main():
         m_g = np.array([sum(1 << b for b in range(32) if not owner[w * 32 + b] and w * 32 + b < n_cu) for w in range(words)], dtype=np.uint32)
         stream = L.d_stream_create_cu_mask(m_s.ctypes.data, words)
         gstream2 = L.d_stream_create_cu_mask(m_g.ctypes.data, words)
-    elif args.stream_priority != "none":
+    elif args.stream_priority != "none" and headline:
         stream = L.d_stream_create_priority(1 if args.stream_priority == "sampler" else 0)
         gstream2 = L.d_stream_create_priority(1 if args.stream_priority == "gather" else 0)
     else:
         stream = L.d_stream_create()       # sampler stream
         gstream2 = L.d_stream_create()     # gather stream of the overlapped schedule (reference: streams_[1], Server.cu:178-181)
-    steps_avail = max(1, (n_mine - 1) // B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
+    steps_avail = c.steps_avail
     K_steps, W = args.steps, args.warmup
 
-    per_level = args.gather == "level" and not intra
+    per_level = args.gather == "level" and not intra and headline
     ev_hop = [L.d_event_create() for _ in range(H + 1)]   # intra: hop h of the running batch is complete
     ev_gdone = L.d_event_create()                          # intra: every gather of the running batch is complete
     intra_started = [False]
@@ -191,6 +378,8 @@ def main():
     ev_sampled = [L.d_event_create() for _ in range(depth)]   # sampling of the batch in pipe q is complete
     ev_gathered = [L.d_event_create() for _ in range(depth)]  # gather of the batch in pipe q is complete
     used = [False] * depth
+
+    census = [True]   # copy nc/ec of the batch into the log (the untimed census pass only: two 64-byte copies cost ~14 us of stream time)
 
     def step(i, timed_idx=None, overlap=overlap):
         """One mini-batch.  overlap: depth-2 pipes (the reference's PIPELINE_DEPTH), the sampler of batch
@@ -213,8 +402,9 @@ def main():
             L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
             if per_level:
                 L.get_feature_kernel(stream, eng.cache, eng.noder, pool, me, 2 * h + 3, 1)
-        L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
-        L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
+        if census[0]:
+            L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
+            L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
         if not per_level:
             if overlap:
                 L.d_event_record(ev_sampled[q], stream)
@@ -254,8 +444,9 @@ def main():
                 L.d_event_record(ev[timed_idx][1], gstream2)
         L.d_event_record(ev_gdone, gstream2)
         intra_started[0] = True
-        L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
-        L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
+        if census[0]:
+            L.d_copy_async(log.ptr + i * 128, o["nc"].ptr, 64, stream)
+            L.d_copy_async(log.ptr + i * 128 + 64, o["ec"].ptr, 64, stream)
         L.make_update_plan(stream, eng.graph, eng.cache, pool, me, K.TRAINMODE)
         L.update_cache(stream, eng.cache, eng.noder, pool, me, K.TRAINMODE)
 
@@ -264,18 +455,37 @@ def main():
         L.d_stream_sync(gstream2)
         torch.cuda.synchronize()
 
+    def window(**kw):
+        """EXACTLY K steps between (synchronize + barrier) and (synchronize + barrier)."""
+        drain()
+        D.barrier(world)
+        t_start = time.perf_counter()
+        for i in range(K_steps):
+            step(W + i, timed_idx=i, **kw)
+        drain()
+        el = time.perf_counter() - t_start
+        D.barrier(world)
+        return el
+
     for i in range(W):
         step(i)
-    drain()
-    if world > 1:
-        torch.distributed.barrier()
-    t_start = time.perf_counter()
+    # census (untimed): the K batches of the timed windows once with their counters logged -- what the windows produce
+    # (edges, rows, algorithmic bytes).  The windows replay exactly these batches without the instrumentation.
     for i in range(K_steps):
-        step(W + i, timed_idx=i)
+        step(W + i)
     drain()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        torch.distributed.barrier()
+    census[0] = False
+    g_ms = []                      # HIP-event time of every timed gather launch (its own stream)
+    windows = [window()]
+    if not per_level:
+        g_ms += [L.d_event_elapsed_ms(a, b) for a, b in ev]
+    # every rank runs the same number of windows: R from the slowest rank's first window
+    first_max, _ = D.aggregate(windows[0], [0.0], world, device=dev)
+    reps = int(min(args.max_reps, max(1, -(-args.min_time // max(first_max, 1e-6)))))
+    for _ in range(reps - 1):
+        windows.append(window())
+        if not per_level:
+            g_ms += [L.d_event_elapsed_ms(a, b) for a, b in ev]
     K.check()
 
     counters = log.to_numpy(np.int32, (K_steps + W) * 32).reshape(K_steps + W, 2, 16)[W:]
@@ -290,30 +500,34 @@ def main():
     gather_bytes = nodes * (8 * F + 8)
     tot_edges, tot_nodes = int(edges.sum()), int(nodes.sum())
 
-    import legion1_amd.dist as D
-    elapsed_max, (job_edges, job_nodes, job_bytes) = D.aggregate(
-        elapsed, [tot_edges, tot_nodes, float(samp_bytes.sum() + gather_bytes.sum())], world, device=dev)
+    # per window: max over ranks; then the median window.  Totals: sum over ranks (every window runs the same K batches)
+    win_max = D.aggregate_max_vec(windows, world, device=dev)
+    _, (job_edges, job_nodes, job_bytes) = D.aggregate(
+        0.0, [tot_edges, tot_nodes, float(samp_bytes.sum() + gather_bytes.sum())], world, device=dev)
+    elapsed_max = float(np.median(win_max))
+
+    leg = dict(unified=unified, cache_info=cache_info, elapsed=elapsed_max, windows=[round(w * 1e3, 4) for w in win_max],
+               job_edges=job_edges, job_nodes=job_nodes, job_bytes=job_bytes, samp_bytes=samp_bytes, gather_bytes=gather_bytes,
+               u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, graph=None,
+               xgmi=None)
 
     # the other schedule on the very same K batches (reported beside the headline, never instead of it)
-    alt = None
-    if not per_level and not intra and not args.headline_only:
-        if world > 1:
-            torch.distributed.barrier()
+    if headline and not per_level and not intra and not args.headline_only:
+        drain()
+        D.barrier(world)
         t_alt = time.perf_counter()
         for i in range(K_steps):
             step(W + i, overlap=not overlap)
         drain()
         alt_elapsed = time.perf_counter() - t_alt
-        if world > 1:
-            torch.distributed.barrier()
+        D.barrier(world)
         alt_max, _ = D.aggregate(alt_elapsed, [0.0], world, device=dev)
-        alt = {"pipeline": "serial" if overlap else "overlap", "ms_per_step": round(alt_max / K_steps * 1e3, 4),
-               "value": round(job_edges / alt_max, 1), "unit": "edges/s",
-               "pipeline_frac": round(job_bytes / alt_max / 1e9 / (HBM_PEAK_GBPS * world), 4)}
+        leg["alt"] = {"pipeline": "serial" if overlap else "overlap", "ms_per_step": round(alt_max / K_steps * 1e3, 4),
+                      "value": round(job_edges / alt_max, 1), "unit": "edges/s",
+                      "pipeline_frac": round(job_bytes / alt_max / 1e9 / (HBM_PEAK_GBPS * world), 4)}
 
     # the serial schedule again, recorded once as a hipGraph and replayed with one launch per batch (same K batches)
-    graph_leg = None
-    if not per_level and not intra and not args.headline_only and world == 1:   # informational leg: N = 1 only, never fatal
+    if headline and not per_level and not intra and not args.headline_only and world == 1:   # informational leg: N = 1 only, never fatal
         try:
             L.legion_set_error_mode(K.ERR_RETURN)     # a HIP error in this leg raises (K.check) instead of exit(1)
             L.GPUMemoryPool_SetCurrentPipe(pool, 0)
@@ -324,110 +538,116 @@ def main():
                 eng.run_graph(hgraph, (W + i) % steps_avail, sync=False)
             drain()
             g_max = time.perf_counter() - t_g
-            graph_leg = {"pipeline": "serial, one hipGraph launch per batch", "ms_per_step": round(g_max / K_steps * 1e3, 4),
-                         "value": round(job_edges / g_max, 1), "unit": "edges/s"}
+            leg["graph"] = {"pipeline": "serial, one hipGraph launch per batch", "ms_per_step": round(g_max / K_steps * 1e3, 4),
+                            "value": round(job_edges / g_max, 1), "unit": "edges/s"}
         except Exception as ex:   # noqa: BLE001 -- the headline line must still be printed
-            graph_leg = {"error": repr(ex)[:200]}
+            leg["graph"] = {"error": repr(ex)[:200]}
         finally:
             L.legion_set_error_mode(K.ERR_EXIT)
 
-    # dominant kernel (k_gather: it moves ~94 % of the batch's algorithmic bytes), HIP events on its stream
-    roofline = None
-    if not per_level:
-        g_ms = np.array([L.d_event_elapsed_ms(a, b) for a, b in ev], dtype=np.float64)
-        if intra:   # the timed launches are the last level's gather: its rows are the new nodes of hop H
-            gather_launch_bytes = u_h[H - 1] * (8 * F + 8)
-        else:
-            gather_launch_bytes = gather_bytes
-        ach = float(gather_launch_bytes.sum()) / (g_ms.sum() * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))   # newest round last
-        pmc = pmcs[-1] if pmcs else ""
-        if args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and fan == [25, 10, 5] and not unified and not intra and args.table == "device" and os.path.exists(pmc):
-            # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-            # command (counters cannot be read from inside the process); gfx950 FETCH_SIZE x2 correction applied
-            with open(pmc) as f:
-                traffic = json.load(f)["k_gather"]["traffic_bytes_per_launch"]
-            traffic_src = "profiles/" + os.path.basename(pmc)
-        roofline = dict(bound="hbm", kernel="k_gather<float4, non-temporal>", achieved=round(ach, 1),
-                        peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
-                        traffic_source=traffic_src, avg_launch_us=round(float(g_ms.mean()) * 1e3, 2),
-                        algorithmic_bytes_per_launch=int(gather_launch_bytes.mean()),
-                        launch="last level (hop %d rows) of the per-level gathers" % H if intra else "all rows of the batch",
-                        pipeline_frac=round(job_bytes / elapsed_max / 1e9 / (HBM_PEAK_GBPS * world), 4))
-
-    xgmi = None
-    if unified and roofline is not None:
-        xgmi = unified_cache_traffic(K, L, eng, me, world, V, F, cache_info, float(np.mean([L.d_event_elapsed_ms(a, b) for a, b in ev])), dev)
-    if world > 1:
-        torch.distributed.barrier()   # nobody unmaps a cache shard while a peer may still read it
-
-    # measured streaming-copy rate of this box (float4 copy kernel, read + write bytes), printed beside the vendor peak
-    copy_gbps = None
-    if rank == 0:
-        nbytes = 4 << 30
-        a_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        b_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        e0, e1 = L.d_event_create(), L.d_event_create()
-        L.legion_copy_f4(stream, b_buf.data_ptr(), a_buf.data_ptr(), nbytes)
-        L.d_event_record(e0, stream)
-        for _ in range(5):
-            L.legion_copy_f4(stream, b_buf.data_ptr(), a_buf.data_ptr(), nbytes)
-        L.d_event_record(e1, stream)
-        copy_gbps = round(5 * 2 * nbytes / (L.d_event_elapsed_ms(e0, e1) * 1e-3) / 1e9, 1)
-        del a_buf, b_buf
-        if roofline is not None:
-            roofline["measured_copy_GBps"] = copy_gbps
-            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbps, 4)
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
-        if host_table is not None:   # the table already is host memory: view it, no copy
-            import ctypes
-            feats = np.ctypeslib.as_array(ctypes.cast(host_table, ctypes.POINTER(ctypes.c_float)), shape=(V, F))
-        try:
-            cpu_baseline = run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail)
-        except Exception as ex:   # noqa: BLE001 -- reported baseline only: never lose the headline line over it
-            cpu_baseline = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
-
-    if rank == 0:
-        out = {
-            # BASELINE.json's metric on its own workload (value = sampled edges/s, the feature GB/s is "feature_GBps")
-            "metric": "sampled edges/s + feature GB/s, 3-hop GraphSAGE ogbn-papers100M at 1/2/4/8 GPU"
-                      if (H == 3 and args.workload == "papers100M" and args.scale == 1.0)
-                      else f"sampled edges/s + feature GB/s, {H}-hop GraphSAGE mini-batch pipeline ({spec.name} shape)",
-            "value": round(job_edges / elapsed_max, 1),
-            "unit": "edges/s",
-            "n_gpus": world,
-            "steps": K_steps,
-            "warmup": W,
-            "ms_per_step": round(elapsed_max / K_steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "int32 ids / f32 rows (verbatim copy)",
-            "data": "synthetic",
-            "config": {"workload": f"{spec.name}-shape synthetic graph, {H}-hop fan-out {fan}, batch {B}, CSR " + ("+ features resident in HBM" if args.table == "device" else "in HBM, features in pinned host memory (PCIe zero-copy)") + (" (Kg=1 replicas)" if not unified else f", unified feature cache over the {world}-GPU clique"),
-                       "V": V, "E": E, "F": F, "batch": B, "fanout": fan, "gather": args.gather, "pipeline": args.pipeline if args.gather == "all" else "serial", "seeds_per_rank": n_mine,
-                       "parallelism": f"dp{world} (seed shards tid % {world}, no data-path collective)"},
-            "feature_GBps": round(job_nodes * 4 * F / elapsed_max / 1e9, 2),
-            "batches_per_s": round(K_steps * world / elapsed_max, 2),
-            "edges_per_batch": round(job_edges / (K_steps * world), 1),
-            "unique_nodes_per_batch": round(job_nodes / (K_steps * world), 1),
-            "sampler_algorithmic_bytes_per_batch": int(samp_bytes.mean()),   # 20 N_h + 28 E_h + 8 U_h summed over the hops
-            "gather_algorithmic_bytes_per_batch": int(gather_bytes.mean()),
-            "graph_gen_s": round(gen_s, 2),
-            "alt_schedule": alt,
-            "graph_replay": graph_leg,
-            "cache": {"mode": args.cache, **(cache_info or {}), **(xgmi or {})},
-            "roofline": roofline,
-            "cpu_baseline": cpu_baseline,
-        }
-        print(json.dumps(out), flush=True)
+    if unified and not per_level:
+        leg["xgmi"] = unified_cache_traffic(c, eng, me, cache_info, float(leg["g_ms"].mean()))
+    D.barrier(world)   # nobody unmaps a cache shard while a peer may still read it
+    drain()
     eng.close()
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    log.free()
+    return leg
+
+
+def roofline_of(c, leg):
+    """Dominant kernel (k_gather: it moves ~94 % of the batch's algorithmic bytes), HIP events on its stream."""
+    args, F, H = c.args, c.spec.F, c.H
+    if leg["per_level"]:
+        return None
+    g_ms = leg["g_ms"]
+    reps = len(g_ms) // args.steps
+    if leg["intra"]:   # the timed launches are the last level's gather: its rows are the new nodes of hop H
+        launch_bytes = leg["u_h"][H - 1] * (8 * F + 8)
+    else:
+        launch_bytes = leg["gather_bytes"]
+    ach = float(launch_bytes.sum()) * reps / (g_ms.sum() * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))   # newest round last
+    pmc = pmcs[-1] if pmcs else ""
+    default_shape = (args.workload == "papers100M" and args.scale == 1.0 and args.batch == 8000 and c.fan == [25, 10, 5] and args.task == "node"
+                     and not leg["unified"] and not leg["intra"] and args.table == "device" and args.skew == 205)
+    if default_shape and os.path.exists(pmc):
+        # HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, collected by
+        # profiles/make_pmc_traffic.py (counters cannot be read from inside the process); gfx950 FETCH_SIZE x2 correction applied
+        with open(pmc) as f:
+            traffic = json.load(f)["k_gather"]["traffic_bytes_per_launch"]
+        traffic_src = "profiles/" + os.path.basename(pmc)
+    return dict(bound="hbm", kernel="k_gather<float4, non-temporal>", achieved=round(ach, 1),
+                peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
+                traffic_measured_in_run=False if traffic is not None else None,
+                traffic_source=(traffic_src + " (separate rocprofv3 --pmc passes of this command; not measured by the run that printed this line)") if traffic_src else None,
+                avg_launch_us=round(float(g_ms.mean()) * 1e3, 2), timed_launches=int(len(g_ms)),
+                algorithmic_bytes_per_launch=int(launch_bytes.mean()),
+                launch="last level (hop %d rows) of the per-level gathers" % H if leg["intra"] else "all rows of the batch",
+                pipeline_frac=round(leg["job_bytes"] / leg["elapsed"] / 1e9 / (HBM_PEAK_GBPS * c.world), 4))
+
+
+def headline_line(c, leg):
+    args, spec, H, F, B, fan, world = c.args, c.spec, c.H, c.spec.F, c.B, c.fan, c.world
+    K_steps = args.steps
+    el = leg["elapsed"]
+    unified = leg["unified"]
+    task = "" if args.task == "node" else ", link-prediction [src|pos|neg] seed batches"
+    return {
+        # BASELINE.json's metric on its own workload (value = sampled edges/s, the feature GB/s is "feature_GBps")
+        "metric": "sampled edges/s + feature GB/s, 3-hop GraphSAGE ogbn-papers100M at 1/2/4/8 GPU"
+                  if (H == 3 and args.workload == "papers100M" and args.scale == 1.0 and args.task == "node")
+                  else f"sampled edges/s + feature GB/s, {H}-hop GraphSAGE mini-batch pipeline ({spec.name} shape{task})",
+        "value": round(leg["job_edges"] / el, 1),
+        "unit": "edges/s",
+        "n_gpus": world,
+        "steps": K_steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(el / K_steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32 ids / f32 rows (verbatim copy)",
+        "data": "synthetic",
+        "config": {"workload": f"{spec.name}-shape synthetic graph{task}, {H}-hop fan-out {fan}, batch {B}, CSR "
+                               + ("+ features resident in HBM" if args.table == "device" else "in HBM, features in pinned host memory (PCIe zero-copy)")
+                               + (" (Kg=1 replicas)" if not unified else f", unified feature cache over the {world}-GPU clique")
+                               + ("" if args.skew == 205 else f", neighbour skew {args.skew}/256"),
+                   "V": spec.V, "E": c.E, "F": F, "batch": B, "fanout": fan, "gather": args.gather,
+                   "pipeline": args.pipeline if args.gather == "all" else "serial", "seeds_per_rank": c.n_mine, "task": args.task,
+                   "parallelism": f"dp{world} (seed shards tid % {world}, no data-path collective)"},
+        "timing": {"windows": len(leg["windows"]), "steps_per_window": K_steps, "window_ms": leg["windows"],
+                   "reported": "median window, max over ranks per window"},
+        "feature_GBps": round(leg["job_nodes"] * 4 * F / el / 1e9, 2),
+        "batches_per_s": round(K_steps * world / el, 2),
+        "edges_per_batch": round(leg["job_edges"] / (K_steps * world), 1),
+        "unique_nodes_per_batch": round(leg["job_nodes"] / (K_steps * world), 1),
+        "sampler_algorithmic_bytes_per_batch": int(leg["samp_bytes"].mean()),   # 20 N_h + 28 E_h + 8 U_h summed over the hops
+        "gather_algorithmic_bytes_per_batch": int(leg["gather_bytes"].mean()),
+        "graph_gen_s": round(c.gen_s, 2),
+        "alt_schedule": leg["alt"],
+        "graph_replay": leg["graph"],
+        "cache": {"mode": "unified" if unified else "replicated", **(leg["cache_info"] or {}), **(leg["xgmi"] or {})},
+        "roofline": roofline_of(c, leg),
+        "cpu_baseline": None,
+    }
+
+
+def unified_summary(c, leg):
+    """The unified-cache leg as one object of the headline line (N > 1)."""
+    args, F = c.args, c.spec.F
+    el = leg["elapsed"]
+    g = leg["g_ms"]
+    reps = max(1, len(g) // args.steps)
+    ach = float(leg["gather_bytes"].sum()) * reps / (g.sum() * 1e-3) / 1e9 if len(g) else None
+    return {"what": f"same seeds and batches, unified feature cache over the {c.world}-GPU clique (Kg={c.world}: rank-t hot row on GPU t % {c.world}), "
+                    "peer shards read in-kernel over xGMI, misses from the local HBM replica",
+            "value": round(leg["job_edges"] / el, 1), "unit": "edges/s", "ms_per_step": round(el / args.steps * 1e3, 4),
+            "feature_GBps": round(leg["job_nodes"] * 4 * F / el / 1e9, 2),
+            "gather_avg_launch_us": round(float(g.mean()) * 1e3, 2) if len(g) else None,
+            "gather_frac_of_hbm_peak": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
+            "windows": len(leg["windows"]), **(leg["cache_info"] or {}), **(leg["xgmi"] or {})}
 
 
 def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
@@ -452,23 +672,25 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
     topo_rows = (int(V * args.topo_frac) // world + 1) if args.topo_frac > 0 else 0
     eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=topo_rows, train_step=args.presc_steps)
     everyone = D.allgather_object(eng.export_shards(me), world)
+    t_imp = time.time()
     for turn in range(world):          # one importer at a time
         if turn == me:
-            t_imp = time.time()
             for g in range(world):
                 if g != me:
                     eng.import_shards(g, everyone[g])
-            if os.environ.get("LEGION_BENCH_WATCHDOG"):
-                print(f"[rank {me}] imported {world - 1} shard(s) of {rows * F * 4 / 1e9:.1f} GB in {time.time() - t_imp:.2f} s", flush=True)
         D.barrier(world)
     return {"Kg": world, "rows_per_gpu": rows, "cached_fraction_of_V": round(rows * world / V, 4), "presc_steps": args.presc_steps,
+            "shard_import_s": round(time.time() - t_imp, 2),
             "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)" if topo_rows == 0 else
                         f"hottest {topo_rows} adjacency rows per GPU in partitioned CSR fragments (owner/row lookup fused into the sampler), rest from the replica",
             "topo_rows_per_gpu": topo_rows}
 
 
-def unified_cache_traffic(K, L, eng, me, world, V, F, cache_info, gather_ms, dev):
-    """Where the rows of the last batch came from: own shard / peer shards (xGMI) / backing table."""
+def unified_cache_traffic(c, eng, me, cache_info, gather_ms):
+    """Where the rows of this rank's last batch came from (own shard / peer shards / backing table), summed over the
+    ranks, and the peer-read rate per GPU that follows from the gather's HIP-event time."""
+    import torch
+    K, L, D, V, F, world, dev = c.K, c.L, c.D, c.spec.V, c.spec.F, c.world, c.dev
     o = eng.out[me][0]
     nc = o["nc"].to_numpy(np.int32, 16)
     n = int(nc[0])
@@ -481,15 +703,49 @@ def unified_cache_traffic(K, L, eng, me, world, V, F, cache_info, gather_ms, dev
     local = int(((slot >= 0) & (owner == me)).sum().item())
     peer = int(((slot >= 0) & (owner != me)).sum().item())
     miss = int((slot < 0).sum().item())
-    return {"rows_last_batch": {"own_shard": local, "peer_shards": peer, "backing_table": miss},
-            "xgmi_read_GBps_per_gpu": round(peer * 4 * F / (gather_ms * 1e-3) / 1e9, 1) if world > 1 else 0.0,
-            "xgmi_peak_GBps_per_gpu": 7 * 153}
+    del fmap, slot, owner, ids
+    rate = peer * 4 * F / (gather_ms * 1e-3) / 1e9                      # this rank's peer-shard read rate
+    _, (s_local, s_peer, s_miss, s_rate) = D.aggregate(0.0, [local, peer, miss, rate], world, device=dev)
+    rmin = D.aggregate_max_vec([-rate], world, device=dev)[0] * -1.0
+    out = {"rows_last_batch": {"own_shard": int(s_local), "peer_shards": int(s_peer), "backing_table": int(s_miss), "summed_over_ranks": world}}
+    if c.shared_device or world == 1:
+        # rehearsal: every rank sits on ONE GPU, a "peer" shard is the same device's HBM -- this is not an xGMI number
+        out.update({"xgmi_read_GBps_per_gpu": None, "xgmi_frac_of_peak": None,
+                    "peer_shard_read_GBps_same_device": round(s_rate / world, 1) if world > 1 else 0.0})
+    else:
+        out.update({"xgmi_read_GBps_per_gpu": round(s_rate / world, 1), "xgmi_read_GBps_min_rank": round(rmin, 1),
+                    "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBPS, "xgmi_frac_of_peak": round(s_rate / world / XGMI_PEAK_GBPS, 4),
+                    "xgmi_note": "peer rows x 4F bytes / the gather's HIP-event time (the gather also reads own-shard and replica rows in that time)"})
+    return out
+
+
+def measure_copy(c):
+    """Streaming float4 copy sized like the gather (non-temporal, one 16-byte chunk per lane and iteration, 1 GiB in,
+    1 GiB out per launch + a 4 GiB pair): what a pure HBM stream reaches on this box.  Printed beside the vendor peak;
+    the gather of skewed ids may exceed it because re-touched hot rows are served by the Infinity Cache."""
+    import torch
+    L, dev = c.L, c.dev
+    best = 0.0
+    for nbytes in (1 << 30, 4 << 30):
+        a_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        b_buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        e0, e1 = L.d_event_create(), L.d_event_create()
+        L.legion_copy_f4(None, b_buf.data_ptr(), a_buf.data_ptr(), nbytes)
+        L.d_event_record(e0, None)
+        for _ in range(5):
+            L.legion_copy_f4(None, b_buf.data_ptr(), a_buf.data_ptr(), nbytes)
+        L.d_event_record(e1, None)
+        L.d_stream_sync(None)
+        best = max(best, 5 * 2 * nbytes / (L.d_event_elapsed_ms(e0, e1) * 1e-3) / 1e9)
+        del a_buf, b_buf
+    return round(best, 1)
 
 
 def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail):
     """The CPU oracle (reference semantics, scalar C, 1 thread) timed on the host cores on a bounded
     sample of the SAME workload: the first few batches of rank 0's seed list."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
     import oracle as O
     t0 = time.time()
     h_indptr = indptr.cpu().numpy()
@@ -515,7 +771,7 @@ def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan
         budget = min(10.0, args.cpu_baseline_seconds)
         try:
             import dgl  # noqa: F401
-            dgl_like = run_dgl_baseline(dgl, h_indptr, h_indices, h_feats, h_ids, B, fan, budget)
+            dgl_like = run_dgl_baseline(dgl, torch, h_indptr, h_indices, h_feats, h_ids, B, fan, budget)
         except ImportError:
             smp = O.DglSemanticsSampler(h_indptr, h_indices, h_feats, spec.V, spec.F, B, fan)
             e2, n2, t2 = 0, 0, 0.0
@@ -538,7 +794,7 @@ def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan
             "seconds": round(t_used, 2), "host_copy_s": round(copy_s, 1), "host_cores_available": os.cpu_count()}
 
 
-def run_dgl_baseline(dgl, indptr, indices, feats, ids, B, fan, budget):
+def run_dgl_baseline(dgl, torch, indptr, indices, feats, ids, B, fan, budget):
     """DGL's own CPU NeighborSampler + feature index_select on the same graph (only if dgl is installed)."""
     g = dgl.graph(("csc", (torch.from_numpy(indptr), torch.from_numpy(indices), torch.tensor([], dtype=torch.int64))))
     sampler = dgl.dataloading.NeighborSampler(list(reversed(fan)))   # DGL lists fan-outs input layer first
@@ -554,6 +810,17 @@ def run_dgl_baseline(dgl, indptr, indices, feats, ids, B, fan, budget):
         n += 1
     return {"value": round(e / t, 1), "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "dgl.dataloading.NeighborSampler (CPU)",
             "sample": f"{n} batches", "seconds": round(t, 2)}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    plan = launch_plan(args, os.environ)
+    if plan.startswith("error"):
+        raise SystemExit("bench.py: " + plan[7:])
+    if plan == "spawn":
+        raise SystemExit(launch_children(args, argv))
+    worker(args)
 
 
 if __name__ == "__main__":

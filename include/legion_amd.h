@@ -259,6 +259,13 @@ void GPUCache_SetPreSc(GPUCache* c, int is_presc);
 void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph);
 int32_t GPUCache_MaxIdNum(const GPUCache* c, int32_t dev_id);
 float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);
+/* HIP-IPC size limit.  No single allocation larger than $LEGION_IPC_MAX_BYTES (default 1.5 GiB) is exported or
+ * imported: on this pool's dmabuf-only IPC hipIpcOpenMemHandle never returned for single allocations of 3.6 GB and
+ * 7.1 GB while 1.78 GB opened at once (profiles/r01_unified_ipc_notes.md).  The Export / Import calls and the trainer hand-off
+ * buffers (IPCEnv_Initialize*Buffer) refuse larger ones with a sticky error (LEGION_ERR_EXIT: the server exits
+ * non-zero instead of leaving a trainer stalled in ipc_service.initialize()).  Shards and fragments are therefore
+ * lists of <= $LEGION_SHARD_CHUNK_BYTES (default 1 GiB) chunks. */
+#define LEGION_IPC_MAX_BYTES_DEFAULT 1610612736ll /* 1.5 GiB */
 /* HIP-IPC exchange of a clique member's feature shard (64-byte handle); returns 0 on success */
 int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64);
 int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle64);
@@ -393,6 +400,17 @@ void Server_Delete(Server* s);
 /* ---- synthetic datasets (generator spec: legion-1_amd/synth.py) ----------------------------- */
 void legion_synth_degrees(void* stream, int64_t* deg_out, int32_t v0, int32_t n, const int32_t* ladder_host26);
 void legion_synth_neighbors(void* stream, int32_t* indices_out, int64_t e0, int64_t n, int32_t V, uint32_t M, uint32_t C);
+/* same with n/256 of the neighbours drawn from the Zipf-like skew (205 = the spec; 0 = uniform: the control run that
+ * shows how much of the gather's rate is Infinity-Cache reuse of hot rows) */
+void legion_synth_neighbors_skew(void* stream, int32_t* indices_out, int64_t e0, int64_t n, int32_t V, uint32_t M, uint32_t C,
+                                 int32_t skew_of_256);
+/* Link-prediction seed batches for lp_sage.py:87-90 ([src | pos | neg] thirds per batch of `batch_size`; the reference
+ * server has no edge / negative sampler).  Triple j: src = srcs[j], pos / neg from the minstd stream at
+ * 48271^(seed + 2*triple_no[j] + 1) -- triple_no = the triple's number in the global order, so the per-GPU lists of a
+ * G-GPU job (triples dealt by src % G) hold exactly the triples of the 1-GPU list.  out: ceil(n/k)*batch_size ids,
+ * k = batch_size/3; device pointers.  Same rule in numpy: legion-1_amd/synth.py lp_trainingset. */
+void legion_synth_lp_seeds(void* stream, int32_t* out, const int32_t* srcs, const int64_t* triple_no, int64_t n_triples,
+                           int32_t batch_size, const int64_t* indptr, const int32_t* indices, int32_t V, uint32_t seed);
 void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F);
 void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int32_t classes);
 void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, int32_t V, uint32_t M2, uint32_t C2, int32_t stride, int32_t phase);

@@ -195,6 +195,8 @@ _SIGS = {
     "Server_Delete": (None, [vp]),
     "legion_synth_degrees": (None, [vp, vp, i32, i32, vp]),
     "legion_synth_neighbors": (None, [vp, vp, i64, i64, i32, u32, u32]),
+    "legion_synth_neighbors_skew": (None, [vp, vp, i64, i64, i32, u32, u32, i32]),
+    "legion_synth_lp_seeds": (None, [vp, vp, vp, vp, i64, i32, vp, vp, i32, u32]),
     "legion_synth_features": (None, [vp, vp, i64, i64, i32]),
     "legion_synth_labels": (None, [vp, vp, i32, i32, i32]),
     "legion_synth_seed_ids": (None, [vp, vp, i64, i64, i32, u32, u32, i32, i32]),

@@ -298,8 +298,11 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
         if (counters) total_trans_of_topo = counters[0] + counters[1];
         else total_trans_of_topo = h_edge_prefix[V - 1]; // PCM-free estimate
         uint64_t total_trans_of_feat = 0;
+        // The reference sums cache_controller_[j]->MaxIdNum() for j < Kg -- the members of the FIRST clique -- for every
+        // clique i (GPUCache.cu:677-680: index j, not i * Kg + j).  Restated as is: the capacities of cliques >= 1 depend
+        // on it whenever the GPUs saw different batch sizes.  (A member another process drives: this clique's home GPU.)
         for (int j = 0; j < Kg; j++)
-            total_trans_of_feat += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, is_remote_device(i * Kg + j) ? home : i * Kg + j) * train_step * F * (int64_t)sizeof(float)) / max_payload_size);
+            total_trans_of_feat += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, is_remote_device(j) ? home : j) * train_step * F * (int64_t)sizeof(float)) / max_payload_size);
 
         int64_t current_mem = 0;
         const int64_t steps = (total_mem - 1) / memory_step + 1;
@@ -416,6 +419,7 @@ int GPUCache_ExportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk,
     if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || c->cache_imported[dev_id] || chunk < 0 ||
         chunk >= (int)c->shard_chunks[dev_id].size()) { LEGION_ARG_ERROR("ExportFeatureShardChunk: no such local chunk"); return -1; }
     DeviceGuard guard(dev_id);
+    if (!ipc_export_ok(c->shard_chunks[dev_id][chunk], "ExportFeatureShardChunk")) return -1;
     HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, c->shard_chunks[dev_id][chunk]));
     return error_pending() ? -1 : 0;
 }
@@ -423,6 +427,11 @@ int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk,
 {
     if (!c || !handle64 || dev_id < 0 || dev_id >= c->device_count || !is_remote_device(dev_id) || c->nchunks.empty() || chunk < 0 ||
         chunk >= c->nchunks[dev_id / c->Kg]) { LEGION_ARG_ERROR("ImportFeatureShardChunk: dev_id must be a remote member, chunk in range"); return -1; }
+    {   // what the exporter allocated for this chunk: 2^shift rows (the last chunk may be shorter)
+        const int Ki = dev_id / c->Kg;
+        const int64_t rows = std::min<int64_t>(1ll << c->chunk_shift[Ki], std::max<int64_t>(1, c->node_capacity[Ki]));
+        if (!ipc_size_ok(rows * c->float_attr_len * (int64_t)sizeof(float), "ImportFeatureShardChunk")) return -1;
+    }
     hipIpcMemHandle_t h;
     memcpy(&h, handle64, sizeof(h));
     void* p = nullptr;

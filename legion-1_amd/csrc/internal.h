@@ -14,6 +14,10 @@ namespace legion {
 // ---- error handling (reference: cudaCheckError(), Kernels.cuh:14-22) -------------------------
 void report_error(const char* file, int line, const char* msg, bool hip_failure);
 bool error_pending();
+bool error_is_fatal();                                     // LEGION_ERR_EXIT mode (the reference's behaviour)
+int64_t ipc_max_bytes();                                   // $LEGION_IPC_MAX_BYTES, see runtime.cpp
+bool ipc_size_ok(int64_t bytes, const char* who);          // sticky error + false above the limit
+bool ipc_export_ok(const void* ptr, const char* who);      // same, for the allocation `ptr` belongs to
 inline void check(hipError_t e, const char* file, int line)
 {
     if (e != hipSuccess) report_error(file, line, hipGetErrorString(e), true);
@@ -40,6 +44,29 @@ constexpr uint32_t kProvisional = 0x80000000u; // | slot idx : claimed in the ru
 constexpr int kTile = LEGION_KTILE;            // sampler slots per workgroup tile
 constexpr int kBlock = 256;                    // threads per workgroup
 constexpr int kMaxParts = LEGION_MAX_DEVICE;
+
+// minstd_rand arithmetic (thrust::minstd_rand: x <- 48271 x mod 2^31-1), shared by the sampler and the generators
+constexpr uint32_t kP31 = 2147483647u; // minstd modulus 2^31 - 1
+constexpr uint32_t kA = 48271u;        // minstd multiplier
+
+__host__ __device__ inline uint32_t mulmod31(uint32_t a, uint32_t b)
+{
+    uint64_t p = (uint64_t)a * (uint64_t)b;
+    uint32_t r = (uint32_t)(p & kP31) + (uint32_t)(p >> 31); // < 2^32
+    r = (r & kP31) + (r >> 31);
+    return r >= kP31 ? r - kP31 : r;
+}
+
+__host__ __device__ inline uint32_t powmod31(uint32_t base, uint64_t e)
+{
+    uint32_t r = 1;
+    while (e) {
+        if (e & 1) r = mulmod31(r, base);
+        base = mulmod31(base, base);
+        e >>= 1;
+    }
+    return r;
+}
 
 // unsigned division by a runtime constant (host precomputed): q = (n * m) >> 32 >> s, n < 2^31
 struct FastDiv {
@@ -80,8 +107,8 @@ struct SamplerBuffers {
     unsigned long long* pos_map; // u64[V]: (epoch << 32) | value
     const BatchCtl* ctl;    // ctl->epoch = 0xFFFFFFFF - batch serial: newer batches compare smaller
     int32_t* cand;          // i32[max slots of a hop]
-    int32_t* aux;           // i32[max slots of a hop], slot state: -1 claim pending / won, >= 0 known position, <= -2 lost to slot -2-x
-    int32_t* aux_next;      // the other buffer: k_resolve prepares it (-1) for the next hop
+    int32_t* aux;           // i32[max slots of a hop], slot state: -1 claim pending / won (k_mark: winner rank), >= 0 known position, <= -2 lost to slot -2-x
+    int32_t* aux_next;      // the other buffer: k_write prepares it (-1) for the next hop
     int32_t next_count;     // fan-out of the next hop (0: none)
     int32_t aux_cap;        // elements per aux buffer
     bool aux_prepared;      // aux already holds -1 for nc[2] * count slots

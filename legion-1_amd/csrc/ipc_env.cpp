@@ -139,6 +139,12 @@ int32_t IPCEnv_GetMaxStep(IPCEnv* e) { return ((e->train_step + e->valid_step) *
 static void* ipc_alloc(volatile shmStruct* shm, int dev, int pipe, int which, size_t bytes)
 {
     void* p = nullptr;
+    // a trainer would stall forever inside ipc_service.initialize() on a buffer it cannot import
+    if (!ipc_size_ok((int64_t)bytes, which == 1 ? "InitializeFeaturesBuffer (rows x F x 4 bytes of one pipe)" : "InitializeSamplesBuffer")) {
+        if (!error_is_fatal()) return nullptr;
+        fflush(stderr);
+        exit(EXIT_FAILURE);
+    }
     HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
     if (p) HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm->memHandle[dev][pipe][which], p));
     return p;
@@ -182,8 +188,11 @@ void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_
     (void)batch_size;
     if (!e || device_id < 0 || device_id >= e->device_count) { LEGION_ARG_ERROR("InitializeFeaturesBuffer: bad arguments"); return; }
     DeviceGuard guard(device_id);
-    for (int32_t i = 0; i < pipeline_depth; i++)
-        e->float_features[device_id].push_back(ipc_alloc(e->shm, device_id, i, 1, (size_t)num_ids * feature_dim * sizeof(float)));
+    for (int32_t i = 0; i < pipeline_depth; i++) {
+        void* p = ipc_alloc(e->shm, device_id, i, 1, (size_t)num_ids * feature_dim * sizeof(float));
+        if (!p) return;   // refused (size limit) or out of memory: the error is sticky, nothing is registered
+        e->float_features[device_id].push_back(p);
+    }
 }
 
 int32_t IPCEnv_GetRawBatchsize(IPCEnv* e) { return e->raw_batch_size; }

@@ -5,7 +5,7 @@
 //   S2 update_counter                 Kernels.cu:112-150    -> folded into k_seed / k_write (last tile)
 //   S3 kernel_random_sampler_2        Kernels.cu:342-448    -> k_sample + k_mark + k_write
 //   S3' kernel_pre_sampler_optimized  Kernels.cu:468-564    -> k_sample<PRESC>
-//   S4 construct_graph                Kernels.cu:450-463    -> k_write (dst side) + k_resolve (src side)
+//   S4 construct_graph                Kernels.cu:450-463    -> k_write (both sides)
 //   S5 zero_copy_with_aggregated_cache Kernels.cu:662-702   -> k_gather (+ k_row_ptrs in front of a cached gather)
 //   S6 FindFeat/FindTopo (BGHT find)  GPUCache.cu:387-461   -> direct-mapped int32/int8[V] tables
 //   S7 ClearPosMap / HotnessMeasure   Kernels.cu:750-756, GPUCache.cu:227-235
@@ -19,13 +19,15 @@
 //                 aux[idx]: -1 claim pending / won, >= 0 the neighbour's known final position,
 //                 <= -2 lost to slot -2-x.  Repeated draws of a row are settled in-wave; a claim that
 //                 replaces a larger slot's claim writes that slot's state ("you lost to me");
-//      k_mark   : streaming count of the states still at -1 = new nodes per tile (no table probe);
-//      k_write  : every workgroup sums the tile counts in front of its tile (no scan launch), then
-//                 ordered compaction (wave ballot + popcount prefix, one LDS exchange per tile)
-//                 appends edges / new nodes at their canonical positions and the COO offsets; the
-//                 workgroup of the last tile applies update_counter (S2);
-//      k_resolve: src-side COO offsets of the edges that lost their claim, following loser -> winner
-//                 through the slot states; prepares the next hop's states (-1).
+//      k_mark   : streaming pass over the states: a slot still at -1 kept its claim = a new node; it gets its
+//                 rank among the new nodes of its tile, the tile its count (no table probe);
+//      k_write  : every workgroup builds the exclusive prefix of the tile counts in LDS (no scan launch),
+//                 then ordered compaction (wave ballot + popcount prefix, one LDS exchange per tile)
+//                 appends edges / new nodes at their canonical positions and both COO offsets -- an edge
+//                 that lost its claim follows loser -> winner through the slot states and computes the
+//                 winner's position from that tile's prefix + rank; it also sets the next hop's states
+//                 to -1; the workgroup of the last tile applies update_counter (S2).
+//    Three launches per hop (round 1: four), 11 per 3-hop batch with k_seed and the gather.
 //  * One u64[V] "position table" replaces accessed_map (bitmap) + position_map.  Entry =
 //    (epoch << 32) | value, epoch = 0xFFFFFFFF - batch serial, so entries of older batches compare
 //    GREATER than anything of the running batch: they are stale without ever being cleared (no
@@ -47,28 +49,6 @@ namespace legion {
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kP31 = 2147483647u; // minstd modulus 2^31 - 1
-constexpr uint32_t kA = 48271u;        // minstd multiplier
-
-__host__ __device__ inline uint32_t mulmod31(uint32_t a, uint32_t b)
-{
-    uint64_t p = (uint64_t)a * (uint64_t)b;
-    uint32_t r = (uint32_t)(p & kP31) + (uint32_t)(p >> 31); // < 2^32
-    r = (r & kP31) + (r >> 31);
-    return r >= kP31 ? r - kP31 : r;
-}
-
-__host__ __device__ inline uint32_t powmod31(uint32_t base, uint64_t e)
-{
-    uint32_t r = 1;
-    while (e) {
-        if (e & 1) r = mulmod31(r, base);
-        base = mulmod31(base, base);
-        e >>= 1;
-    }
-    return r;
-}
-
 // thrust::uniform_int_distribution<int>(0, deg-1) fed with x = minstd value (Kernels.cu:402-405;
 // thrust/random/detail/uniform_int_distribution.inl:73-89, uniform_real_distribution.inl:71-79)
 __device__ inline int32_t sample_index(uint32_t x, int32_t deg)
@@ -301,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                     if (cur < prov0) known = (int32_t)(uint32_t)cur;
                     // a smaller claim of this hop is in the table: this slot has lost for good (claims only
                     // decrease).  Point at that slot; if it loses later too, its own aux points further, and
-                    // k_resolve follows the chain to the winner.
+                    // k_write follows the chain to the winner.
                     else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & 0x7FFFFFFFu);
                 }
                 cnt++;
@@ -332,18 +312,28 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-// S3 pass 2 -- flag the winners (bit 31 of cand), count new nodes per tile
+// S3 pass 2 -- rank the winners inside their tile, count new nodes per tile
 // ------------------------------------------------------------------------------------------------
-// aux[idx] (written by k_sample) = the neighbour's final position when it was already known (node seen in
-// an earlier hop / seed), else -1.  Only the other slots probe the table here: a slot whose claim
-// survived is the winner of a new node.
+// A slot whose state is still -1 after k_sample kept its claim: it discovered a new node.  Its state becomes
+// "winner, r-th new node of this tile" (enc_win): with the per-tile counts that is the node's final position,
+// computable by ANY workgroup of k_write -- which is what lets k_write resolve the edges that lost their claim
+// itself (round 1 needed a fourth launch per hop, k_resolve, for that).
+constexpr int32_t kWinBase = 0x40000000;
+constexpr int kWriteEntries = 12288;    // k_write keeps <= 52 KB of tile prefix in LDS (one entry per tile up to 12.6 M slots per hop) // loser states are -2 - slot with slot < 2^30; winners sit below them
+__device__ inline int32_t enc_win(int32_t r) { return -2 - (kWinBase + r); }
+__device__ inline bool is_win(int32_t v) { return v <= -2 - kWinBase; }
+__device__ inline int32_t win_rank(int32_t v) { return -2 - v - kWinBase; }
+
 __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, const int32_t* __restrict__ ec,
-                                                 int32_t count, const int32_t* __restrict__ aux,
+                                                 int32_t count, int32_t* __restrict__ aux,
                                                  int32_t* __restrict__ tile_node, HopState* __restrict__ hs)
 {
-    __shared__ int32_t s_cnt[kBlock / 64];
+    constexpr int S = kTile / kBlock, W = kBlock / 64;
+    __shared__ int32_t s_c[S * W];
     const int32_t total = nc[2] * count;
     const int32_t n_tiles = (total + kTile - 1) / kTile;
+    const int lane = lane_id(), wave = wave_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // hop-start snapshot of the counters: k_write's last tile applies update_counter in place, so
         // its other workgroups must not read the live nc/ec
@@ -353,22 +343,29 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
         *hs = h;
     }
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        // a slot whose state is still -1 after k_sample kept its claim: it discovered a new node
-        int32_t cnt = 0;
+        bool win[S];
+        int32_t rk[S];
 #pragma unroll
-        for (int s = 0; s < kTile / kBlock; s++) {
+        for (int s = 0; s < S; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            if (idx < total && aux[idx] == -1) cnt++;
+            win[s] = idx < total && aux[idx] == -1;
+            const unsigned long long b = __ballot(win[s]);
+            rk[s] = __popcll(b & lt);
+            if (lane == 0) s_c[s * W + wave] = __popcll(b);
         }
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-        if (lane_id() == 0) s_cnt[wave_id()] = cnt;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int32_t t = 0;
+        int32_t run = 0, before[S];
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) t += s_cnt[w];
-            tile_node[tile] = t;
+        for (int q = 0; q < S * W; q++) { // slot order inside a tile: s-major, then wave, then lane
+#pragma unroll
+            for (int s = 0; s < S; s++)
+                if (q == s * W + wave) before[s] = run;
+            run += s_c[q];
         }
+#pragma unroll
+        for (int s = 0; s < S; s++)
+            if (win[s]) aux[tile * kTile + threadIdx.x + kBlock * s] = enc_win(before[s] + rk[s]);
+        if (threadIdx.x == 0) tile_node[tile] = run;
         __syncthreads();
     }
 }
@@ -393,7 +390,7 @@ __device__ inline void apply_update_counter(int32_t* nc, int32_t* ec, int32_t op
 }
 
 // ------------------------------------------------------------------------------------------------
-// S3 pass 4 -- ordered compaction: edges, new nodes, dst-side COO offsets
+// S3 pass 3 + S4 -- ordered compaction: edges, new nodes, both COO offsets; next hop's slot states
 // ------------------------------------------------------------------------------------------------
 struct WriteArgs {
     HopState* hs;
@@ -401,7 +398,7 @@ struct WriteArgs {
     int32_t* ec;
     int32_t hops;
     const int32_t* cand;
-    int32_t* aux;
+    const int32_t* aux;     // slot states after k_mark: >= 0 known position, winner rank (enc_win), -2 - <slot it lost to>
     const int32_t* tile_edge;
     const int32_t* tile_node;
     int32_t* sampled_ids;
@@ -412,15 +409,29 @@ struct WriteArgs {
     FastDiv fdiv;
     int32_t op_id;
     const BatchCtl* ctl;
-    int32_t last_hop; // positions of the nodes found in the last hop are never looked up through the table
+    int32_t last_hop;       // positions of the nodes found in the last hop are never looked up through the table
+    int32_t gshift;         // the LDS prefix holds one entry per 2^gshift tiles (sized from the static slot bound)
+    int32_t lds_entries;    // entries of the dynamic LDS prefix array
+    int32_t lpb;            // log2 of the groups per prefix block: min(5, 6 - gshift)
+    int32_t* aux_next;      // slot states of the next hop (the other buffer), set to "claim pending" here
+    int32_t next_count;     // fan-out of the next hop (0: none)
+    int32_t aux_cap;
 };
 
 __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
 {
     constexpr int S = kTile / kBlock, W = kBlock / 64;
+    // Exclusive prefix of the per-tile edge and new-node counts, once per workgroup, in LDS: the workgroup needs it for
+    // its own tiles AND (nodes) for the tile of any winner one of its losing edges points at -- no scan launch, no
+    // inter-workgroup hand-off (device-scope fences cost an L2 write-back + invalidate per XCD: profiles/r01_gather_sweep.md).
+    // Layout: one entry per group of 2^gshift tiles (gshift == 0 unless the hop's static bound exceeds kWriteEntries
+    // tiles), groups in blocks of kPB = 2^lpb: s_tile[g] = (edges | nodes << 16) in front of group g INSIDE its block
+    // (both < 2^16: kPB * 2^gshift <= 64 tiles of <= 1024), s_blk[b] = (edges, nodes) in front of block b.
+    extern __shared__ uint32_t s_tile[];
+    int2* const s_blk = reinterpret_cast<int2*>(s_tile + a.lds_entries);
+    const int32_t lpb = a.lpb, kPB = 1 << lpb;
     __shared__ int32_t s_e[S * W];
-    __shared__ int32_t s_n[S * W];
-    __shared__ int32_t s_pre[2][W];
+    __shared__ int2 s_scan[W];
     const HopState h = *a.hs;
     const uint32_t epoch = a.ctl->epoch;
     const int32_t total = h.slots;
@@ -431,93 +442,140 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
         if (blockIdx.x == 0 && threadIdx.x == 0) apply_update_counter(a.nc, a.ec, a.op_id, a.hops, 0, 0);
         return;
     }
+    if ((int32_t)blockIdx.x >= n_tiles) return;
+    const int32_t gmask = (1 << a.gshift) - 1;
+    const int32_t n_groups = (n_tiles + gmask) >> a.gshift;
+    const int32_t n_blocks = (n_groups + kPB - 1) >> lpb;
+    {
+        // a wave scans 64 / kPB blocks per step: lane l owns group (l & (kPB - 1)) of block b0 + (l >> lpb)
+        // (coalesced loads, segmented shuffle scan)
+        const int32_t bpw = 64 >> lpb, sub = lane & (kPB - 1);
+        for (int32_t b0 = wave * bpw; b0 < n_blocks; b0 += bpw * W) {
+            const int32_t blk = b0 + (lane >> lpb);
+            const int32_t g = blk * kPB + sub;
+            int32_t ve = 0, vn = 0;
+            if (g < n_groups) {
+                const int32_t te = min((g + 1) << a.gshift, n_tiles);
+                for (int32_t t = g << a.gshift; t < te; t++) { ve += a.tile_edge[t]; vn += a.tile_node[t]; }
+            }
+            int32_t ie = ve, in = vn;
+            for (int o = 1; o < kPB; o <<= 1) {
+                const int32_t ue = __shfl_up(ie, o), un = __shfl_up(in, o);
+                if (sub >= o) { ie += ue; in += un; }
+            }
+            if (g < n_groups) s_tile[g] = (uint32_t)(ie - ve) | ((uint32_t)(in - vn) << 16);
+            if (sub == kPB - 1 && blk < n_blocks) s_blk[blk] = make_int2(ie, in); // block totals
+        }
+        __syncthreads();
+        // exclusive scan of the block totals (a few per thread)
+        const int32_t per = (n_blocks + kBlock - 1) / kBlock;
+        const int32_t q0 = min((int32_t)threadIdx.x * per, n_blocks), q1 = min(q0 + per, n_blocks);
+        int32_t se = 0, sn = 0;
+        for (int32_t q = q0; q < q1; q++) { se += s_blk[q].x; sn += s_blk[q].y; }
+        int32_t ie = se, in = sn;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t ue = __shfl_up(ie, o), un = __shfl_up(in, o);
+            if (lane >= o) { ie += ue; in += un; }
+        }
+        if (lane == 63) s_scan[wave] = make_int2(ie, in);
+        __syncthreads();
+        int32_t run_e = ie - se, run_n = in - sn;
+#pragma unroll
+        for (int w = 0; w < W; w++)
+            if (w < wave) { run_e += s_scan[w].x; run_n += s_scan[w].y; }
+        for (int32_t q = q0; q < q1; q++) { const int2 v = s_blk[q]; s_blk[q] = make_int2(run_e, run_n); run_e += v.x; run_n += v.y; }
+        __syncthreads();
+    }
+    // (edges, new nodes) in front of tile t
+    auto prefix_of = [&](int32_t t, int32_t& pe, int32_t& pn) {
+        const int32_t g = t >> a.gshift;
+        const uint32_t pk = s_tile[g];
+        const int2 bb = s_blk[g >> lpb];
+        pe = bb.x + (int32_t)(pk & 0xFFFFu);
+        pn = bb.y + (int32_t)(pk >> 16);
+        for (int32_t u = t & ~gmask; u < t; u++) { pe += a.tile_edge[u]; pn += a.tile_node[u]; }
+    };
 
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        // exclusive prefix of the tile counts: every workgroup sums the (L2-resident, <= 12 k entries)
-        // count arrays in front of its tile itself -- no scan launch, no inter-workgroup hand-off
-        int32_t pre_e = 0, pre_n = 0;
-        for (int32_t t = threadIdx.x; t < tile; t += kBlock) { pre_e += a.tile_edge[t]; pre_n += a.tile_node[t]; }
-        for (int o = 32; o > 0; o >>= 1) { pre_e += __shfl_xor(pre_e, o); pre_n += __shfl_xor(pre_n, o); }
-        if (lane == 0) { s_pre[0][wave] = pre_e; s_pre[1][wave] = pre_n; }
-        int32_t c[S], ax[S], re[S], rn[S];
+        int32_t pre_e, pre_n;
+        prefix_of(tile, pre_e, pre_n);
+        const int32_t tile_e = a.tile_edge[tile];
+        const int32_t ebase = h.edge_base + pre_e;
+        const int32_t nbase = h.node_base + pre_n;
+        // ---- loads first, all S slots of the thread in flight together (nothing below this block reads global memory) ----
+        int32_t c[S], so[S], dpos[S], w[S], re[S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
             c[s] = (idx < total) ? a.cand[idx] : -1;
-            ax[s] = (idx < total) ? a.aux[idx] : 0;
+            so[s] = (idx < total) ? a.aux[idx] : 0;
         }
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const bool valid = c[s] != -1;
-            const bool isnew = ax[s] == -1; // the slot kept its claim (k_sample): a new node
-            const unsigned long long be = __ballot(valid), bn = __ballot(isnew);
-            re[s] = __popcll(be & lt);
-            rn[s] = __popcll(bn & lt);
-            if (lane == 0) { s_e[s * W + wave] = __popcll(be); s_n[s * W + wave] = __popcll(bn); }
-        }
-        __syncthreads();
-        pre_e = 0; pre_n = 0;
-#pragma unroll
-        for (int w = 0; w < W; w++) { pre_e += s_pre[0][w]; pre_n += s_pre[1][w]; }
-        const int32_t ebase = h.edge_base + pre_e;
-        const int32_t nbase = h.node_base + pre_n;
-        if (tile == n_tiles - 1 && threadIdx.x == 0) { // hop totals: update_counter + what k_resolve needs
-            const int32_t n_edges = pre_e + a.tile_edge[tile], n_nodes = pre_n + a.tile_node[tile];
-            a.hs->n_edges = n_edges;
-            a.hs->n_nodes = n_nodes;
-            apply_update_counter(a.nc, a.ec, a.op_id, a.hops, n_nodes, n_edges);
-        }
-#pragma unroll
-        for (int s = 0; s < S; s++) {
+            dpos[s] = 0; w[s] = -1;
             if (c[s] == -1) continue;
-            int32_t pe = 0, pn = 0;
-            for (int q = 0; q < s * W + wave; q++) { pe += s_e[q]; pn += s_n[q]; }
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            const int32_t dst = c[s];
-            const int32_t e = ebase + pe + re[s];
-            a.agg_src_ids[e] = dst;
             // dst-side offset = position of the slot's source node; for hops > 1 the sources are the
             // previous hop's edge endpoints, whose positions are that hop's src-side offsets: same value
             // as position_map[src] (construct_graph, Kernels.cu:457-461) without the random read.
             const int32_t i = (int32_t)fdiv((uint32_t)idx, a.fdiv);
             // hop 1: the seed's position.  That is i unless the seed list holds duplicates (link-prediction
             // triples), where the reference's position_map keeps the last occurrence -- read it (<= B*f probes).
-            a.agg_dst_off[e] = (a.op_id == 2) ? (int32_t)(uint32_t)a.pos_map[a.sampled_ids[i]] : a.agg_src_off[h.in_off + i];
-            int32_t so = ax[s]; // known position (>= 0), -2 - <winning slot> (k_resolve reads that slot's aux) or -1: winner
-            if (ax[s] == -1) {
-                const int32_t p = nbase + pn + rn[s];
+            dpos[s] = (a.op_id == 2) ? (int32_t)(uint32_t)a.pos_map[a.sampled_ids[i]] : a.agg_src_off[h.in_off + i];
+            // lost the claim: first link of loser -> (earlier loser ->)* winner or known node
+            if (so[s] < -1 && !is_win(so[s])) { w[s] = -2 - so[s]; so[s] = a.aux[w[s]]; }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) // longer chains are rare: follow them one slot at a time
+            while (w[s] >= 0 && so[s] < -1 && !is_win(so[s])) { w[s] = -2 - so[s]; so[s] = a.aux[w[s]]; }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const unsigned long long be = __ballot(c[s] != -1);
+            re[s] = __popcll(be & lt);
+            if (lane == 0) s_e[s * W + wave] = __popcll(be);
+        }
+        __syncthreads();
+        if (tile == n_tiles - 1 && threadIdx.x == 0) { // hop totals: update_counter (S2)
+            const int32_t n_edges = pre_e + tile_e, n_nodes = pre_n + a.tile_node[tile];
+            a.hs->n_edges = n_edges;
+            a.hs->n_nodes = n_nodes;
+            apply_update_counter(a.nc, a.ec, a.op_id, a.hops, n_nodes, n_edges);
+        }
+        // ---- stores ----
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            if (c[s] == -1) continue;
+            int32_t pe = 0;
+            for (int q = 0; q < s * W + wave; q++) pe += s_e[q];
+            const int32_t dst = c[s];
+            const int32_t e = ebase + pe + re[s];
+            a.agg_src_ids[e] = dst;
+            a.agg_dst_off[e] = dpos[s];
+            // src-side offset (construct_graph, Kernels.cu:456-460) = position of the sampled neighbour
+            int32_t p = so[s];
+            if (w[s] >= 0) {         // an edge that lost its claim
+                if (p < -1) {        // ... to a new node: the winner's position from ITS tile's prefix and its rank
+                    int32_t pe_w, pn_w;
+                    prefix_of(w[s] / kTile, pe_w, pn_w);
+                    p = h.node_base + pn_w + win_rank(p);
+                }
+            } else if (is_win(p)) {  // this slot discovered the node: k_mark ranked it inside the tile
+                p = nbase + win_rank(p);
                 a.sampled_ids[p] = dst;
-                // the winner publishes its position per SLOT (streamed store); the scattered table store
-                // is only needed when a later hop may look the node up by id
-                a.aux[idx] = p;
+                // the scattered table store is only needed when a later hop may look the node up by id
                 if (!a.last_hop) a.pos_map[dst] = ((unsigned long long)epoch << 32) | (uint32_t)p;
-                so = p;
             }
-            a.agg_src_off[e] = so;
+            a.agg_src_off[e] = p;
+        }
+        // The next hop expands this tile's edges into slots [e * f', (e + 1) * f'): their states (the other aux
+        // buffer, last read two launches ago) start as "claim pending"
+        if (a.next_count > 0) {
+            const int64_t lo = min((int64_t)pre_e * a.next_count, (int64_t)a.aux_cap);
+            const int64_t hi = min((int64_t)(pre_e + tile_e) * a.next_count, (int64_t)a.aux_cap);
+            for (int64_t q = lo + threadIdx.x; q < hi; q += kBlock) a.aux_next[q] = -1;
         }
         __syncthreads();
     }
-}
-
-// S4 (src side): agg_src_off[e] = position of the sampled neighbour (construct_graph, Kernels.cu:456-460).
-// k_write already stored it for known nodes and winners; an edge that lost its claim carries
-// -2 - <winning slot>, and that slot's aux now holds the winner's position.
-__global__ __launch_bounds__(kBlock) void k_resolve(const HopState* __restrict__ hs, const int32_t* __restrict__ aux,
-                                                    int32_t* __restrict__ agg_src_off, int32_t* __restrict__ aux_next,
-                                                    int32_t next_count, int32_t aux_cap)
-{
-    const int32_t base = hs->edge_base, n = hs->n_edges;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = threadIdx.x + (int64_t)blockDim.x * blockIdx.x;
-    for (int64_t i = t0; i < n; i += stride) {
-        int32_t so = agg_src_off[base + i];
-        if (so < -1) {
-            do so = aux[-2 - so]; while (so < -1); // loser -> (earlier loser ->)* winner: short chains
-            agg_src_off[base + i] = so;
-        }
-    }
-    // the next hop expands this hop's n edges: its slot states (the other aux buffer) start as "claim pending"
-    const int64_t n_init = min((int64_t)n * next_count, (int64_t)aux_cap);
-    for (int64_t i = t0; i < n_init; i += stride) aux_next[i] = -1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -866,9 +924,18 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     w.hs = b.hop_state; w.nc = b.nc; w.ec = b.ec; w.hops = hops; w.cand = b.cand; w.aux = b.aux; w.ctl = b.ctl; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
     w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
     w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id; w.last_hop = (op_id / 2 == hops) ? 1 : 0;
-    k_write<<<grid, kBlock, 0, s>>>(w);
-    HIP_CHECK_LAST();
-    k_resolve<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.hop_state, b.aux, b.agg_src_off, b.aux_next, b.next_count, b.aux_cap);
+    w.aux_next = b.aux_next; w.next_count = b.next_count; w.aux_cap = b.aux_cap;
+    // LDS prefix: one packed entry per 2^gshift tiles (+ one pair per 32 entries), at most kWriteEntries entries
+    w.gshift = 0;
+    while (((max_tiles + (1 << w.gshift) - 1) >> w.gshift) > kWriteEntries) w.gshift++;
+    if (w.gshift > 6) { LEGION_ARG_ERROR("GPU_Random_Sampling: hop too large for the tile-prefix encoding"); return; }
+    w.lpb = std::min(5, 6 - w.gshift);
+    w.lds_entries = (((max_tiles + (1 << w.gshift) - 1) >> w.gshift) + 63) & ~63;
+    const size_t lds = (size_t)w.lds_entries * sizeof(uint32_t) + (size_t)(w.lds_entries >> w.lpb) * sizeof(int2);
+    // every workgroup builds the prefix once: launch no more of them than are resident together
+    const int per_cu = std::max(1, std::min(8, (int)((140 * 1024) / (lds + 1024))));
+    const int wgrid = grid_for(max_tiles, 1, per_cu);
+    k_write<<<wgrid, kBlock, lds, s>>>(w);
     HIP_CHECK_LAST();
 }
 

@@ -139,7 +139,7 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     b.aux_prepared = p->aux_ready_hop == hop && p->aux_ready_count == count;
     b.next_count = hop < p->hops ? p->fanout[hop] : 0;
     launch_sample_hop((hipStream_t)strm_hdl, csr, b, count, op_id, p->hops, (int32_t)slots, is_presc != 0);
-    p->aux_ready_hop = hop + 1; p->aux_ready_count = b.next_count; // k_resolve prepared the next hop's slot states
+    p->aux_ready_hop = hop + 1; p->aux_ready_count = b.next_count; // k_write prepared the next hop's slot states
     p->bound_n = (int32_t)slots;          // next hop expands every sampled edge endpoint
     p->bound_nodes += (int32_t)slots;
 }

@@ -6,6 +6,7 @@
 // transaction input from the collected hotness instead (cache.cpp).
 #include "internal.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 #include <fcntl.h>
@@ -56,7 +57,11 @@ void Runner_Initialize(Runner* r, RunnerParams* params)
     IPCEnv* env = (IPCEnv*)params->env;
     HIP_CHECK(hipStreamCreateWithFlags(&r->streams[0], hipStreamNonBlocking));
     HIP_CHECK(hipStreamCreateWithFlags(&r->streams[1], hipStreamNonBlocking));
-    const int batch_size = IPCEnv_GetRawBatchsize(env);
+    // the pool serves train, validation and test batches: size it for the largest of the three (the per-GPU
+    // validation / test batch, CUDA_IPC_Service.cu:101-118, can exceed a small raw batch size)
+    int batch_size = IPCEnv_GetRawBatchsize(env);
+    batch_size = std::max(batch_size, IPCEnv_GetCurrentBatchsize(env, r->local_dev_id, LEGION_VALIDMODE));
+    batch_size = std::max(batch_size, IPCEnv_GetCurrentBatchsize(env, r->local_dev_id, LEGION_TESTMODE));
     const int hop_num = params->hops;
     r->hops = hop_num;
     // op list: [BatchGen, Feat, (Samp, Feat) x hops, Planner, Updater]  (Server.cu:198-207)
@@ -202,6 +207,13 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         // the updater (last op, stream 1) is ordered behind every op of the batch through the op events
         if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[1]));
         else HIP_CHECK(hipEventSynchronize(r->events[r->op_num - 1])); // reference: spin on cudaEventQuery
+    }
+    if (error_pending()) {
+        // an operator refused its arguments (sticky error): the buffers of this pipe hold stale data.  Never hand
+        // them to a trainer -- the reference's error behaviour is exit(EXIT_FAILURE) (Kernels.cuh:14-22).
+        std::cout << "Runner_RunOnce: batch " << batch_id << " on GPU " << r->local_dev_id << " failed; server stops\n" << std::flush;
+        if (error_is_fatal()) exit(EXIT_FAILURE);
+        return;
     }
     if (r->pipelined) {
         if (r->pending) { // batch i is queued: now hand batch i-1 to its trainer
@@ -359,9 +371,25 @@ void Server_Initialize(Server* s, int global_shard_count)
     // seed split, GPUGraphStore.cu:332-414
     s->tr_ids.assign(G, {}); s->va_ids.assign(G, {}); s->te_ids.assign(G, {});
     s->tr_lab.assign(G, {}); s->va_lab.assign(G, {}); s->te_lab.assign(G, {});
-    for (int32_t tid : training_ids) {
-        int32_t part = (have_part && m.partition == 1) ? partition_index[tid] : tid % G;
-        if (part < G) s->tr_ids[part].push_back(tid);
+    if (m.partition == 2) {
+        // Pre-partitioned training lists (extension, not in the reference): meta flag 2 = GPU g serves the file
+        // trainingset_<G>_<g> verbatim.  Needed for link prediction on G > 1 GPUs: lp_sage.py:87-90 expects every
+        // batch as [src | pos | neg] thirds, which neither split rule below preserves (synth.lp_trainingset writes them).
+        for (int g = 0; g < G && ok; g++) {
+            const std::string path = m.dataset_path + "trainingset_" + std::to_string(G) + "_" + std::to_string(g);
+            struct stat st;
+            if (stat(path.c_str(), &st) != 0) { std::cout << "cannout open file: " << path << "\n"; ok = false; break; }
+            s->tr_ids[g].resize((size_t)st.st_size / 4);
+            ok = read_file(path, s->tr_ids[g].data(), (int64_t)s->tr_ids[g].size() * 4);
+            for (int32_t tid : s->tr_ids[g]) if (tid < 0 || tid >= V) ok = false;
+        }
+        if (!ok) { LEGION_ARG_ERROR("Server_Initialize: pre-partitioned training lists (meta flag 2) missing or out of range"); return; }
+    } else {
+        for (int32_t tid : training_ids) {
+            if (tid < 0 || tid >= V) { LEGION_ARG_ERROR("Server_Initialize: training id outside [0, V)"); return; }
+            int32_t part = (have_part && m.partition == 1) ? partition_index[tid] : tid % G;
+            if (part >= 0 && part < G) s->tr_ids[part].push_back(tid); // the reference indexes unchecked (GPUGraphStore.cu:338-341)
+        }
     }
     for (int32_t tid : validation_ids) { int32_t part = tid % G; if (part < G) s->va_ids[part].push_back(tid); }
     for (int32_t tid : testing_ids) { int32_t part = tid % G; if (part < G) s->te_ids[part].push_back(tid); }

@@ -30,6 +30,34 @@ void report_error(const char* file, int line, const char* msg, bool hip_failure)
 }
 
 bool error_pending() { return !t_last_error.empty(); }
+bool error_is_fatal() { return g_error_mode == LEGION_ERR_EXIT; }
+
+// Largest single allocation that may cross a process boundary as a HIP IPC handle.  On this pool (dmabuf-only IPC,
+// HSA_ENABLE_IPC_MODE_LEGACY=0) hipIpcOpenMemHandle never returned for one allocation of 3.6 GB and of 7.1 GB, while
+// 1.78 GB (and every <= 1 GiB chunk since) opened at once (profiles/r01_unified_ipc_notes.md).  The threshold sits
+// somewhere in between (2 GiB is the obvious suspect); 1.5 GiB is below everything that is known to work.
+int64_t ipc_max_bytes()
+{
+    const char* e = getenv("LEGION_IPC_MAX_BYTES");
+    return e && atoll(e) > 0 ? atoll(e) : LEGION_IPC_MAX_BYTES_DEFAULT;
+}
+bool ipc_size_ok(int64_t bytes, const char* who)
+{
+    if (bytes <= ipc_max_bytes()) return true;
+    char msg[320];
+    snprintf(msg, sizeof(msg), "%s: a single allocation of %lld bytes exceeds the HIP-IPC limit of %lld bytes (LEGION_IPC_MAX_BYTES): "
+             "larger single allocations never finish importing on this driver; use the chunked calls / a smaller buffer",
+             who, (long long)bytes, (long long)ipc_max_bytes());
+    report_error(__FILE__, __LINE__, msg, false);
+    return false;
+}
+bool ipc_export_ok(const void* ptr, const char* who)
+{
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return ipc_size_ok((int64_t)size, who);
+}
 
 bool is_remote_device(int logical) { return logical >= 0 && logical < 64 && g_remote[logical]; }
 

@@ -2,6 +2,7 @@
 // GPUMemoryNodeStorage (GPU_Memory_Node_Storage.cu:3-207) and GPUMemoryPool (GPUMemoryPool.cuh:7-208).
 #include "internal.h"
 
+#include <algorithm>
 #include <cstring>
 #include <set>
 
@@ -283,6 +284,7 @@ int GPUGraphStorage_ExportFragmentChunk(GPUGraphStorage* g, int32_t dev_id, int3
     void* p = GPUGraphStorage_GetFragmentChunk(g, dev_id, which, chunk);
     if (!p || !handle64 || g->frag[dev_id].imported) { LEGION_ARG_ERROR("ExportFragmentChunk: no such local chunk"); return -1; }
     DeviceGuard guard(dev_id);
+    if (!ipc_export_ok(p, "ExportFragmentChunk")) return -1;
     HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, p));
     return error_pending() ? -1 : 0;
 }
@@ -300,6 +302,11 @@ int GPUGraphStorage_ImportFragmentChunk(GPUGraphStorage* g, int32_t owner_dev, i
     const int n = which == 0 ? (int)f.ip.size() : (int)f.ix.size();
     if (chunk < 0 || chunk >= n) { LEGION_ARG_ERROR("ImportFragmentChunk: chunk out of range"); return -1; }
     void*& slot = which == 0 ? (void*&)f.ip[chunk] : (void*&)f.ix[chunk];
+    {   // lower bound of what the exporter allocated for this chunk
+        const int64_t bytes = which == 0 ? (std::min<int64_t>(rows, 1ll << g->row_shift) + 1) * (int64_t)sizeof(int64_t)
+                                         : std::min<int64_t>(edges, 1ll << g->edge_shift) * (int64_t)sizeof(int32_t);
+        if (!slot && !ipc_size_ok(bytes, "ImportFragmentChunk")) return -1;
+    }
     if (!slot) {
         DeviceGuard guard(viewer_dev);
         hipIpcMemHandle_t h;
@@ -457,6 +464,7 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
         if (cur > max_slots) max_slots = cur;
         ids += cur;
         if (ids >= (1ll << 31)) { LEGION_ARG_ERROR("GPUMemoryPool_AllocateScratch: batch*fanouts exceeds int32"); return; }
+        if (cur >= (1ll << 30)) { LEGION_ARG_ERROR("GPUMemoryPool_AllocateScratch: a hop of 2^30 or more slots exceeds the slot-state encoding"); return; }
         p->level_bound[h + 1] = (int32_t)cur;
     }
     p->num_ids = (int32_t)ids;

@@ -33,13 +33,13 @@ __global__ void k_synth_degrees(int64_t* out, int32_t v0, int32_t n, Ladder lad)
     }
 }
 
-__global__ void k_synth_neighbors(int32_t* out, int64_t e0, int64_t n, uint32_t V, uint32_t M, uint32_t C)
+__global__ void k_synth_neighbors(int32_t* out, int64_t e0, int64_t n, uint32_t V, uint32_t M, uint32_t C, uint32_t skew)
 {
     for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t h = sm64(S_NBR + (uint64_t)(e0 + i));
         const uint64_t a = h >> 32;
         uint64_t x = a;
-        if ((h & 0xFF) < 205) x = (((a * a) >> 32) * a) >> 32;
+        if ((h & 0xFF) < skew) x = (((a * a) >> 32) * a) >> 32;
         const uint64_t r = (x * (uint64_t)V) >> 32;
         out[i] = (int32_t)((r * (uint64_t)M + (uint64_t)C) % (uint64_t)V);
     }
@@ -69,6 +69,33 @@ __global__ void k_synth_seed_ids(int32_t* out, int64_t i0, int64_t n, uint32_t V
     for (int64_t k = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t i = (uint64_t)(i0 + phase + k * stride);
         out[k] = (int32_t)((i * (uint64_t)M2 + (uint64_t)C2) % (uint64_t)V);
+    }
+}
+
+// Link-prediction seed batches (lp_sage.py:87-90 splits a batch into [src | pos | neg] thirds; the reference server
+// has no edge / negative sampler, so the seed list itself is laid out that way -- legion-1_amd/synth.py
+// lp_trainingset is the numpy statement of the same rule).  Triple j of this list: src = srcs[j]; with
+// t = triple_no[j] its number in the global (all ranks) triple order, pos = a neighbour of src drawn with minstd value
+// 48271^(seed + 2t + 1), neg = a uniform node id from the next value.  k = batch / 3 triples per batch; the tail of the
+// last batch repeats that batch's first triple.
+__global__ void k_synth_lp_seeds(int32_t* out, const int32_t* srcs, const int64_t* triple_no, int64_t n, int32_t batch,
+                                 const int64_t* indptr, const int32_t* indices, uint32_t V, uint32_t seed)
+{
+    const int64_t k = batch / 3, n_pad = (n + k - 1) / k * k;
+    for (int64_t j = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; j < n_pad; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = j / k, i = j - b * k;
+        const int64_t jj = j < n ? j : b * k;       // padding: the first triple of the last batch
+        const int32_t s = srcs[jj];
+        const uint64_t t = (uint64_t)triple_no[jj];
+        uint32_t x = powmod31(kA, (uint64_t)seed + 2ull * t + 1ull);
+        const int64_t lo = indptr[s], hi = indptr[s + 1];
+        int32_t pos = s;
+        if (hi > lo) { pos = indices[lo + (int64_t)((x - 1u) % (uint64_t)(hi - lo))]; if (pos < 0) pos = s; }
+        x = mulmod31(x, kA);
+        const int32_t neg = (int32_t)((x - 1u) % V);
+        out[b * batch + i] = s;
+        out[b * batch + k + i] = pos;
+        out[b * batch + 2 * k + i] = neg;
     }
 }
 
@@ -110,10 +137,24 @@ void legion_synth_degrees(void* stream, int64_t* deg_out, int32_t v0, int32_t n,
     k_synth_degrees<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(deg_out, v0, n, lad);
     HIP_CHECK_LAST();
 }
-void legion_synth_neighbors(void* stream, int32_t* indices_out, int64_t e0, int64_t n, int32_t V, uint32_t M, uint32_t C)
+void legion_synth_neighbors_skew(void* stream, int32_t* indices_out, int64_t e0, int64_t n, int32_t V, uint32_t M, uint32_t C,
+                                 int32_t skew_of_256)
 {
     if (n <= 0) return;
-    k_synth_neighbors<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(indices_out, e0, n, (uint32_t)V, M, C);
+    k_synth_neighbors<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(indices_out, e0, n, (uint32_t)V, M, C, (uint32_t)skew_of_256);
+    HIP_CHECK_LAST();
+}
+void legion_synth_neighbors(void* stream, int32_t* indices_out, int64_t e0, int64_t n, int32_t V, uint32_t M, uint32_t C)
+{
+    legion_synth_neighbors_skew(stream, indices_out, e0, n, V, M, C, 205); // the spec'd 80 % Zipf-like neighbours
+}
+void legion_synth_lp_seeds(void* stream, int32_t* out, const int32_t* srcs, const int64_t* triple_no, int64_t n_triples,
+                           int32_t batch_size, const int64_t* indptr, const int32_t* indices, int32_t V, uint32_t seed)
+{
+    if (n_triples <= 0) return;
+    if (batch_size < 3 || batch_size % 3) { LEGION_ARG_ERROR("legion_synth_lp_seeds: batch size must be a multiple of 3"); return; }
+    k_synth_lp_seeds<<<big_grid(n_triples), 256, 0, (hipStream_t)stream>>>(out, srcs, triple_no, n_triples, batch_size, indptr, indices,
+                                                                           (uint32_t)V, seed);
     HIP_CHECK_LAST();
 }
 void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F)

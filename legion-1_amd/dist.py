@@ -49,6 +49,19 @@ def aggregate(elapsed_s: float, totals, world: int, device=None):
     return float(t.item()), [float(x) for x in s.tolist()]
 
 
+def aggregate_max_vec(values, world: int, device=None):
+    """Element-wise MAX over ranks of a list of floats (per-window elapsed times: every rank runs the same windows)."""
+    if world <= 1:
+        return [float(v) for v in values]
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() != "nccl":
+        device = None
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.tolist()]
+
+
 def throughput_line(job_units: float, elapsed_max_s: float, steps: int):
     """whole-job units/s and ms per step from the aggregated numbers."""
     return job_units / elapsed_max_s, elapsed_max_s / steps * 1e3

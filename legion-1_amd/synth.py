@@ -265,37 +265,58 @@ def meta_config_line(ds: Dataset, path: str, batch_size: int, cache_bytes: int, 
                                                     epochs, partition_flag)
 
 
-def lp_trainingset(ds: Dataset, n_triples: int, batch_size: int, seed: int = 1) -> np.ndarray:
+def minstd_pow(exp) -> np.ndarray:
+    """48271**exp mod (2**31 - 1) for a uint64 array of exponents (square and multiply, vectorised)."""
+    m = _U64(2147483647)
+    e = np.asarray(exp, dtype=np.uint64).copy()
+    r = np.ones(e.shape, dtype=np.uint64)
+    b = np.full(e.shape, 48271, dtype=np.uint64)
+    while e.size and e.any():
+        odd = (e & _U64(1)).astype(bool)
+        r = np.where(odd, (r * b) % m, r)
+        b = (b * b) % m
+        e >>= _U64(1)
+    return r
+
+
+def lp_trainingset(ds: Dataset, n_triples: int, batch_size: int, seed: int = 1, rank: int = 0, world: int = 1) -> np.ndarray:
     """Seed list for the link-prediction trainer (reference: pytorch_extension/lp_sage.py:87-90).
 
     lp_sage.py splits the model output of a batch into three equal thirds ``[src | pos | neg]``; the
     reference server has no edge / negative sampler, so the seed file itself must be laid out that way.
     Every batch of ``batch_size`` (a multiple of 3) seeds is ``k = batch_size/3`` source nodes, then for
-    each of them one positive (a neighbour drawn with the sampler's own minstd stream: slot index =
-    global triple number) and one negative (uniform node id from the next minstd value).  Duplicates
-    inside a batch are legal: the pipeline keeps the reference's "last occurrence wins" position rule.
+    each of them one positive (a neighbour drawn with the sampler's own minstd stream: value
+    ``48271**(seed + 2t + 1)`` for global triple ``t``) and one negative (uniform node id from the next
+    minstd value).  Duplicates inside a batch are legal: the pipeline keeps the reference's "last
+    occurrence wins" position rule.
+
+    ``world > 1``: the list of GPU ``rank``.  The reference's ``tid % G`` split of one seed file would shred
+    the thirds, so the triples are dealt by ``src % world`` (order preserved) and every GPU gets a list of
+    its own whose batches keep the layout; the triples of all lists together are those of the 1-GPU list.
+    csrc/synth.hip ``legion_synth_lp_seeds`` is the same rule on the GPU (bit-identical, tested).
     """
     assert batch_size % 3 == 0
     k = batch_size // 3
-    m31 = 2147483647
-    out = np.empty((n_triples + k - 1) // k * batch_size, dtype=np.int32)
-    srcs = ds.train[np.arange(n_triples) % len(ds.train)]
-    x = pow(48271, seed, m31)
-    for t in range(n_triples):
-        s = int(srcs[t])
-        lo, hi = int(ds.indptr[s]), int(ds.indptr[s + 1])
-        x = (x * 48271) % m31
-        pos = int(ds.indices[lo + (x - 1) % (hi - lo)]) if hi > lo else s
-        x = (x * 48271) % m31
-        neg = (x - 1) % ds.spec.V
-        b, i = divmod(t, k)
-        out[b * batch_size + i] = s
-        out[b * batch_size + k + i] = pos if pos >= 0 else s
-        out[b * batch_size + 2 * k + i] = neg
-    tail = n_triples % k
-    if tail:                     # pad the last batch by repeating its first triple
-        b = n_triples // k
-        for i in range(tail, k):
-            for part in range(3):
-                out[b * batch_size + part * k + i] = out[b * batch_size + part * k]
+    t = np.arange(n_triples, dtype=np.int64)
+    srcs = ds.train[t % len(ds.train)].astype(np.int64)
+    if world > 1:
+        sel = (srcs % world) == rank
+        t, srcs = t[sel], srcs[sel]
+    n = len(t)
+    x1 = minstd_pow(np.uint64(seed) + _U64(2) * t.astype(np.uint64) + _U64(1))
+    x2 = (x1 * _U64(48271)) % _U64(2147483647)
+    lo, hi = ds.indptr[srcs], ds.indptr[srcs + 1]
+    deg = hi - lo
+    pick = lo + ((x1 - _U64(1)) % np.maximum(deg, 1).astype(np.uint64)).astype(np.int64)
+    pos = np.where(deg > 0, ds.indices[np.minimum(pick, len(ds.indices) - 1)], srcs)
+    pos = np.where(pos < 0, srcs, pos)
+    neg = ((x2 - _U64(1)) % _U64(ds.spec.V)).astype(np.int64)
+    n_pad = (n + k - 1) // k * k
+    j = np.arange(n_pad)
+    jj = np.where(j < n, j, (j // k) * k)            # pad the last batch by repeating its first triple
+    out = np.empty(n_pad // k * batch_size, dtype=np.int32)
+    b, i = j // k, j % k
+    out[b * batch_size + i] = srcs[jj]
+    out[b * batch_size + k + i] = pos[jj]
+    out[b * batch_size + 2 * k + i] = neg[jj]
     return out

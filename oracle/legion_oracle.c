@@ -390,7 +390,9 @@ void lo_candidate_selection(const uint64_t *const *access, int32_t Kg, int32_t V
 /* Inputs: AF/AT = hotness sorted descending (from candidate selection), QT =
  * topology rank order, csr_index = host indptr, counters[2] = the two PCIe
  * read-transaction counters the reference takes from Intel PCM (Server.cu:100),
- * max_ids[j] = MaxIdNum of clique GPU j.  Outputs node/edge capacity per GPU,
+ * max_ids[j] = cache_controller_[j]->MaxIdNum(), j < Kg: the reference indexes
+ * GPU j, i.e. the members of the FIRST clique, whichever clique is being solved
+ * (GPUCache.cu:677-680) -- callers pass those.  Outputs node/edge capacity per GPU,
  * alpha step index and the winning transaction figure.
  * Restated literally: float accumulators, `steps` arithmetic, the `< V` guards
  * that leave trans_* at 0 once everything fits (GPUCache.cu:744-751), and

@@ -43,6 +43,8 @@ def main():
         recs.append(dict(b=b, n=int(ids.shape[0]), sizes=list(sizes), ids=sha(ids), features=sha(feats), labels=sha(labels),
                          edges=[int(blocks[2 * k].numel()) for k in range(hops)],
                          src=sha(blocks[0]), dst=sha(blocks[1])))
+        if os.environ.get("LEGION_CLIENT_DUMP_SEEDS"):   # the seed part of the batch: ids[0 : batch size]
+            recs[-1]["seeds"] = ids[:labels.shape[0]].cpu().tolist()
         ipc_service.synchronize()
     ipc_service.finalize()
     with open(out, "w") as f:

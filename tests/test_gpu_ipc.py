@@ -221,3 +221,106 @@ def test_torch_link_prediction_trainer_on_triple_seeds(tmp_path, synth):
             server.kill()
     losses = [float(l.split("Train Loss:")[1].split(",")[0]) for l in tr.stdout.splitlines() if l.startswith("Epoch:")]
     assert len(losses) == epochs and losses[-1] < 1.2 < 2 * np.log(2) + 0.2, tr.stdout
+
+
+def _serve(tmp_path, spec, meta_line, fan, G, agg_mode, epochs, extra_env=None, client_env=None):
+    """Start `legion G agg_mode fan meta`, one ipc_client per GPU; returns ([client json per GPU], server log text)."""
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write(meta_line)
+    ns = "s%d_%d_" % (os.getpid(), abs(hash(str(tmp_path))) % 100000)
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([SERVER, str(G), str(agg_mode), ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,
+                                  env=env, cwd=str(tmp_path))
+    clients = []
+    try:
+        _wait_ready(server, log)
+        for g in range(G):
+            out = str(tmp_path / ("client%d.json" % g))
+            clients.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_client.py"), str(spec.F), str(epochs), out],
+                                                  env=dict(env, LEGION_IPC_DEVICE=str(g), **(client_env or {})), stdout=subprocess.PIPE,
+                                                  stderr=subprocess.STDOUT, text=True)))
+        for out, c in clients:
+            stdout, _ = c.communicate(timeout=300)
+            assert c.returncode == 0, stdout[-3000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        for _, c in clients:
+            if c.poll() is None:
+                c.kill()
+        if server.poll() is None:
+            server.kill()
+    return [json.load(open(out)) for out, _ in clients], open(log).read()
+
+
+def test_two_gpu_server_partition_file_split(tmp_path, synth, oracle):
+    """meta_config flag 1 + partition_2_bn: training seeds go to the GPU the partition file names, validation / test
+    still by tid % G (GPUGraphStore.cu:332-346).  The file is NOT tid % 2, so a server that ignored it would fail."""
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    data = str(tmp_path / "ds") + "/"
+    synth.write_legion_files(ds, data)
+    G, B, epochs, fan = 2, 512, 1, [10, 5]
+    part = ((np.arange(spec.V, dtype=np.int64) // 7) % G).astype("<i4")
+    part.tofile(os.path.join(data, "partition_%d_bn" % G))
+    got, text = _serve(tmp_path, spec, synth.meta_config_line(ds, data, B, 1 << 40, epochs, 1), fan, G, 0, epochs)
+    assert "Partition?:         1" in text
+    tr = oracle.split_seeds(ds.train, G, part, 1)
+    assert not all(np.array_equal(a, b) for a, b in zip(tr, oracle.split_seeds(ds.train, G)))
+    parts = {0: tr, 1: oracle.split_seeds(ds.valid, G), 2: oracle.split_seeds(ds.test, G)}
+    steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)
+    for g in range(G):
+        assert got[g]["steps"] == steps.tolist() and len(got[g]["batches"]) == oracle.max_step(steps, epochs)
+        bs = {0: int(tb[g]), 1: int(vb[g]), 2: int(sb[g])}
+        orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+        for rec in got[g]["batches"]:
+            mode, local = oracle.schedule(steps, epochs, rec["b"])
+            ids = parts[mode][g]
+            ref = orc.run_batch(ids, ds.labels[ids], local, mode=mode, batch_size=bs[mode])
+            assert rec["ids"] == sha(ref["ids"]) and rec["labels"] == sha(ref["labels"]) and rec["features"] == sha(ref["features"])
+            assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
+
+
+def test_two_gpu_server_link_prediction_lists_keep_their_thirds(tmp_path, synth, oracle):
+    """Link prediction on G = 2 GPUs: the reference's `tid % G` split of one seed file shreds the [src | pos | neg]
+    thirds lp_sage.py:87-90 relies on, so the lists are written per GPU (triples dealt by src % G, synth.lp_trainingset)
+    and served verbatim (meta flag 2).  Every train batch a trainer receives must be its list's batch: src third on
+    its own GPU, pos third neighbours of the src third, and the batch bit-identical to the oracle on that list."""
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    data = str(tmp_path / "ds") + "/"
+    synth.write_legion_files(ds, data)
+    G, B, epochs, fan = 2, 513, 1, [10, 5]
+    k, n_triples = B // 3, len(ds.train)
+    lists = [synth.lp_trainingset(ds, n_triples, B, rank=g, world=G) for g in range(G)]
+    for g in range(G):
+        lists[g].astype("<i4").tofile(os.path.join(data, "trainingset_%d_%d" % (G, g)))
+    got, text = _serve(tmp_path, spec, synth.meta_config_line(ds, data, B, 1 << 40, epochs, 2), fan, G, 0, epochs,
+                       client_env={"LEGION_CLIENT_DUMP_SEEDS": "1"})
+    assert "Partition?:         2" in text
+    parts = {0: lists, 1: oracle.split_seeds(ds.valid, G), 2: oracle.split_seeds(ds.test, G)}
+    steps, tb, vb, sb = oracle.coordinate([len(p) for p in lists], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)
+    assert steps[0] >= 2
+    for g in range(G):
+        bs = {0: int(tb[g]), 1: int(vb[g]), 2: int(sb[g])}
+        orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+        n_train = 0
+        for rec in got[g]["batches"]:
+            mode, local = oracle.schedule(steps, epochs, rec["b"])
+            ids = parts[mode][g]
+            ref = orc.run_batch(ids, ds.labels[ids], local, mode=mode, batch_size=bs[mode])
+            assert rec["ids"] == sha(ref["ids"]) and rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
+            if mode != 0:
+                continue
+            n_train += 1
+            seeds = np.array(rec["seeds"], dtype=np.int64)
+            assert np.array_equal(seeds, lists[g][local * B:(local + 1) * B])
+            src, pos = seeds[:k], seeds[k:2 * k]
+            assert (src % G == g).all()
+            for s_, p_ in zip(src[:64], pos[:64]):
+                row = ds.indices[ds.indptr[s_]:ds.indptr[s_ + 1]]
+                assert p_ == s_ or p_ in row
+        assert n_train == steps[0]

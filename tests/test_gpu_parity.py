@@ -281,6 +281,7 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
     # ranking + cost model with explicit counters + fill-up
     eng.build_cache(cache_agg_mode=mode, counters=counters, train_step=steps)
     assert L.GPUCache_Kg(eng.cache) == Kg and L.GPUCache_Kc(eng.cache) == G // Kg
+    pinned_by_indexing = []
     for Ki in range(G // Kg):
         members = list(range(Ki * Kg, (Ki + 1) * Kg))
         AF, QF = oracle.candidate_selection([orcs[m].node_access_time for m in members], V)
@@ -288,7 +289,12 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
         L.SetGPUDevice(Ki * Kg)
         assert np.array_equal(K.read_dev(L.GPUCache_GetQF(eng.cache, Ki), np.int32, V), QF)
         assert np.array_equal(K.read_dev(L.GPUCache_GetQT(eng.cache, Ki), np.int32, V), QT)
-        cm = oracle.cost_model(AF, AT, QT, ds.indptr, V, F, budget, Kg, counters, [max_ids[m] for m in members], steps)
+        # the reference feeds MaxIdNum of GPUs 0..Kg-1 (the FIRST clique) to every clique (GPUCache.cu:677-680); the
+        # G=4/Kg=2 and G=8/Kg=4 cases have two cliques with different max_ids, so this pins the indexing
+        cm = oracle.cost_model(AF, AT, QT, ds.indptr, V, F, budget, Kg, counters, [max_ids[j] for j in range(Kg)], steps)
+        if Ki > 0 and [max_ids[m] for m in members] != [max_ids[j] for j in range(Kg)]:
+            own = oracle.cost_model(AF, AT, QT, ds.indptr, V, F, budget, Kg, counters, [max_ids[m] for m in members], steps)
+            pinned_by_indexing.append((own["node_capacity"], own["edge_capacity"]) != (cm["node_capacity"], cm["edge_capacity"]))
         assert L.GPUCache_NodeCapacity(eng.cache, Ki * Kg) == cm["node_capacity"]
         assert L.GPUCache_EdgeCapacity(eng.cache, Ki * Kg) == cm["edge_capacity"]
         assert abs(L.GPUCache_Alpha(eng.cache, Ki) - cm["alpha_idx"] * 0.01) < 1e-9
@@ -692,3 +698,62 @@ def test_repeatability_under_contention(K, oracle):
         eng.run_batch(0, c, per_level=False)
         assert_batch_equal(refs[c], eng.result(0))
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# HIP-IPC size limit (include/legion_amd.h: LEGION_IPC_MAX_BYTES) and the link-prediction seed generator
+# ---------------------------------------------------------------------------------------------------
+def test_ipc_exports_above_the_limit_are_refused(K, small_ds, monkeypatch):
+    """A single allocation above $LEGION_IPC_MAX_BYTES is never exported / imported (larger ones never finished
+    importing on this driver, profiles/r01_unified_ipc_notes.md): sticky error instead of a stalled trainer."""
+    L = K.lib()
+    ds = small_ds
+    eng = make_engine(K, ds, 100, [5, 3], G=2, train_step=2)
+    for g in range(2):
+        eng.run_batch(g, 0, is_presc=True)
+    eng.build_cache(cache_agg_mode=1, node_capacity=1000, edge_capacity=500, train_step=2)   # 1000 rows x 400 B = 400 kB shards
+    h = C.create_string_buffer(64)
+    assert L.GPUCache_ExportFeatureShardChunk(eng.cache, 0, 0, h) == 0
+    assert L.GPUGraphStorage_ExportFragmentChunk(eng.graph, 0, 1, 0, h) == 0
+    K.check()
+    monkeypatch.setenv("LEGION_IPC_MAX_BYTES", "100000")
+    assert L.GPUCache_ExportFeatureShardChunk(eng.cache, 0, 0, h) == -1
+    with pytest.raises(RuntimeError, match="HIP-IPC limit"):
+        K.check()
+    assert L.GPUCache_ExportFeatureShard(eng.cache, 0, h) == -1
+    with pytest.raises(RuntimeError, match="HIP-IPC limit"):
+        K.check()
+    # the trainer hand-off buffers: 1000 rows x F x 4 bytes per pipe > limit -> refused, nothing allocated
+    env = L.NewIPCEnv(1)
+    L.IPCEnv_InitializeFeaturesBuffer(env, 0, 1000, ds.spec.F, 0, 1)
+    with pytest.raises(RuntimeError, match="HIP-IPC limit"):
+        K.check()
+    monkeypatch.delenv("LEGION_IPC_MAX_BYTES")
+    L.IPCEnv_InitializeFeaturesBuffer(env, 0, 1000, ds.spec.F, 0, 1)
+    K.check()
+    assert L.IPCEnv_GetFloatFeatures(env, 0, 0)
+    L.IPCEnv_Finalize(env)
+    eng.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_lp_seed_generator_matches_numpy(K, synth, small_ds, world):
+    """legion_synth_lp_seeds (what bench.py --task lp uses at the papers100M shape) == synth.lp_trainingset, per rank."""
+    L = K.lib()
+    ds = small_ds
+    B = 96
+    d_ip, d_ix = K.DevBuf.from_numpy(ds.indptr), K.DevBuf.from_numpy(ds.indices)
+    n = len(ds.train) - 5                      # a ragged tail: the last batch is padded
+    for rank in range(world):
+        ref = synth.lp_trainingset(ds, n, B, seed=1, rank=rank, world=world)
+        srcs = ds.train[:n]
+        sel = np.flatnonzero(srcs % world == rank)
+        d_s, d_t = K.DevBuf.from_numpy(srcs[sel].astype(np.int32)), K.DevBuf.from_numpy(sel.astype(np.int64))
+        d_o = K.DevBuf(len(ref) * 4)
+        L.legion_synth_lp_seeds(None, d_o.ptr, d_s.ptr, d_t.ptr, len(sel), B, d_ip.ptr, d_ix.ptr, ds.spec.V, 1)
+        L.d_stream_sync(None)
+        K.check()
+        assert np.array_equal(d_o.to_numpy(np.int32, len(ref)), ref)
+        for b in (d_s, d_t, d_o):
+            b.free()
+    d_ip.free(); d_ix.free()

@@ -1,0 +1,209 @@
+"""BASELINE.json configs 3, 4 and 5 in their stated form and at their full shape, on the one device of the test
+box (the clique's logical GPUs are mapped onto it with legion_set_device_map; on a node the same loads cross xGMI):
+
+  3  papers100M 3-hop, hotness-partitioned unified feature cache over a Kg = 2 clique (default 1 GiB shard chunks)
+  4  uk-union 2-hop, CSR sharded across the clique (partitioned fragments, E = 5.5e9 > 2^32) + features in pinned
+     host memory with a capped HBM cache (hits from both shards, misses spill to the host table over PCIe)
+  5  link prediction on the papers100M shape ([src | pos | neg] seed thirds with duplicates)
+
+The oracle cannot run these sizes in seconds, so the checks are the size-independent properties of tests/props.py plus
+byte equality of every gathered row with the generator's closed form, split by where the row came from."""
+import numpy as np
+import pytest
+
+from conftest import assert_batch_equal
+from props import check_batch, device_graph, device_seeds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    import legion1_amd.capi as K
+    L = K.lib()
+    L.legion_set_error_mode(K.ERR_RETURN)
+    L.SetGPUDevice(0)
+    return K
+
+
+def _clique_engine(K, spec, indptr, indices, feat_ptr, feat_loc, E, parts, B, fan, presc_steps):
+    G = len(parts)
+    L = K.lib()
+    for g in range(G):
+        L.legion_set_device_map(g, 0)
+    seeds = dict(train=[((ids.data_ptr(), int(ids.numel())), (lab.data_ptr(), int(lab.numel()))) for ids, lab in parts])
+    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feat_ptr, spec.V, spec.F, seeds, B, fan, G=G, csr_location=K.LOC_DEVICE,
+                   features_location=feat_loc, E=E, train_step=presc_steps)
+    eng.alloc_features()
+    for g in range(G):                      # pre-sampling epoch (Server.cu:83-95): hotness of nodes and adjacency rows
+        for it in range(presc_steps):
+            eng.run_batch(g, it, is_presc=True)
+    return eng
+
+
+def _row_sources(K, eng, g, ids, cap):
+    """Where FindFeat sends each row of a batch of logical GPU g: own shard / peer shard / backing table."""
+    L = K.lib()
+    L.SetGPUDevice(g)
+    fmap = K.read_dev(L.GPUCache_GetFeatureMap(eng.cache, g), np.int32, eng.V)
+    slot = fmap[ids]
+    own = (slot >= 0) & (slot // cap == g)
+    peer = (slot >= 0) & (slot // cap != g)
+    return own, peer, slot < 0
+
+
+def test_papers100m_unified_cache_kg2_full_shape(K, synth):
+    """Config 3: 25 % of the V feature rows cached by hotness over a 2-GPU clique, 7 x 1 GiB chunks per shard."""
+    L = K.lib()
+    spec, indptr, indices, feats, E = device_graph(K, synth, "papers100M")
+    B, fan, G, presc = 8000, [25, 10, 5], 2, 6
+    parts = device_seeds(K, spec, G)
+    eng = _clique_engine(K, spec, indptr, indices, feats.data_ptr(), K.LOC_DEVICE, E, parts, B, fan, presc)
+    cap = int(spec.V * 0.25) // G + 1
+    eng.build_cache(cache_agg_mode=1, node_capacity=cap, edge_capacity=0, train_step=presc)
+    assert L.GPUCache_Kg(eng.cache) == 2 and L.GPUCache_NodeCapacity(eng.cache, 0) == cap
+    assert L.GPUCache_ShardChunkCount(eng.cache, 0) == L.GPUCache_ShardChunkCount(eng.cache, 1) == 7      # 7.1 GB in 1 GiB chunks
+    rs = np.random.RandomState(3)
+    for g in range(G):
+        seeds_g = parts[g][0].cpu().numpy()
+        for it in (0, presc + 1):           # a batch of the pre-sampling epoch and one the cache has never seen
+            eng.run_batch(g, it, per_level=(it == 0))
+            res = eng.result(g)
+            check_batch(res, spec, synth, B, fan, indptr, indices, seeds_g[it * B:(it + 1) * B], rs)
+            own, peer, miss = _row_sources(K, eng, g, res["ids"], cap)
+            # every node of a pre-sampled batch has hotness > 0 and the cache holds more rows than were ever seen, so
+            # batch 0 is served from the two shards alone; a batch the cache has never seen also misses
+            kinds = (own.sum(), peer.sum(), miss.sum())
+            assert min(kinds[:2]) > 0.05 * len(res["ids"]) and (kinds[2] > 0.05 * len(res["ids"]) if it else kinds[2] == 0), kinds
+            for name, m in (("own", own), ("peer", peer), ("miss", miss)):       # every source serves the right bytes
+                if m.sum() == 0:
+                    continue
+                rows = rs.choice(np.flatnonzero(m), size=1500, replace=False)
+                assert np.array_equal(res["features"][rows], synth.features(spec, res["ids"][rows])), name
+    # the cached rows are the hottest: hit rate well above the cached fraction
+    assert (own.sum() + peer.sum()) / len(res["ids"]) > 0.3
+    eng.close()
+
+
+def test_uk_union_sharded_csr_and_host_spill_full_shape(K, synth):
+    """Config 4: uk-union 2-hop {25,10}; the hottest adjacency rows as partitioned CSR fragments over the Kg = 2 clique
+    (several 1 GiB index chunks per fragment: the row_shift / edge_shift chunk tables are exercised at E > 2^32), the
+    feature table in pinned host memory (137 GB) behind a capped HBM cache."""
+    import torch
+    L = K.lib()
+    spec, indptr, indices, feats, E = device_graph(K, synth, "uk-union")
+    assert E > 2 ** 32
+    V, F = spec.V, spec.F
+    nbytes = V * F * 4
+    host = L.host_alloc_space64(nbytes)
+    if not host:
+        L.legion_clear_error()
+        pytest.skip("no %d GB of pinned host memory on this box" % (nbytes >> 30))
+    L.d_copy_d_2_h(host, feats.data_ptr(), nbytes)
+    K.check()
+    del feats
+    torch.cuda.empty_cache()
+    B, fan, G, presc = 8000, [25, 10], 2, 6
+    parts = device_seeds(K, spec, G)
+    eng = _clique_engine(K, spec, indptr, indices, host, K.LOC_HOST_PINNED, E, parts, B, fan, presc)
+    cap_n, cap_e = int(V * 0.10) // G + 1, int(V * 0.30) // G + 1
+    eng.build_cache(cache_agg_mode=1, node_capacity=cap_n, edge_capacity=cap_e, train_step=presc)
+    for g in range(G):
+        assert L.GPUGraphStorage_FragmentRows(eng.graph, g) == cap_e
+        edges = L.GPUGraphStorage_FragmentEdges(eng.graph, g)
+        nix = L.GPUGraphStorage_FragmentChunkCount(eng.graph, g, 1)
+        assert nix == (edges - 1) // L.GPUGraphStorage_FragmentChunkSpan(eng.graph, 1) + 1 and nix > 1, (edges, nix)
+    rs = np.random.RandomState(4)
+    L.SetGPUDevice(0)
+    owner = np.empty(V, np.int8)
+    d_probe = K.DevBuf.from_numpy(np.arange(V, dtype=np.int32))
+    d_pi, d_po = K.DevBuf(V), K.DevBuf(V * 4)
+    L.GPUCache_FindTopo(eng.cache, d_probe.ptr, d_pi.ptr, d_po.ptr, V, 2, None, 0)
+    L.d_stream_sync(None)
+    owner = d_pi.to_numpy(np.int8, V)
+    for b in (d_probe, d_pi, d_po):
+        b.free()
+    assert (owner == 0).sum() == cap_e and (owner == 1).sum() == cap_e     # rank-t row on GPU t % 2
+    for g in range(G):
+        seeds_g = parts[g][0].cpu().numpy()
+        for it in (1, presc + 2):
+            eng.run_batch(g, it)
+            res = eng.result(g)
+            levels = check_batch(res, spec, synth, B, fan, indptr, indices, seeds_g[it * B:(it + 1) * B], rs)
+            ids = res["ids"]
+            # the sampler expanded rows of all three kinds: own fragment, peer fragment, the whole-CSR replica
+            srcs = ids[:levels[0] + levels[1]]
+            kinds = [(owner[srcs] == g).sum(), (owner[srcs] == 1 - g).sum(), (owner[srcs] < 0).sum()]
+            assert min(kinds[:2]) > 0 and (kinds[2] > 0 or it < presc), kinds    # rows of a pre-sampled batch are all cached
+            own, peer, miss = _row_sources(K, eng, g, ids, cap_n)
+            assert min(own.sum(), peer.sum()) > 0.02 * len(ids) and (miss.sum() > 0.02 * len(ids) or it < presc), (own.sum(), peer.sum(), miss.sum())
+            for name, m in (("own", own), ("peer", peer), ("host", miss)):
+                if m.sum() == 0:
+                    continue
+                rows = rs.choice(np.flatnonzero(m), size=min(1000, int(m.sum())), replace=False)
+                assert np.array_equal(res["features"][rows], synth.features(spec, ids[rows])), name
+    # the same batch again: bit-identical (fragments, cache and host rows are all deterministic sources)
+    eng.run_batch(0, 1)
+    again = eng.result(0)
+    eng.run_batch(0, 1)
+    assert_batch_equal(again, eng.result(0))
+    eng.close()
+    L.host_free_space(host)
+
+
+def test_papers100m_link_prediction_full_shape(K, synth):
+    """Config 5: [src | pos | neg] seed batches at the papers100M shape (11.1 M triples generated on the GPU by
+    legion_synth_lp_seeds, the list of logical GPU 1 of 2: triples dealt by src % 2), 3-hop."""
+    import torch
+    L = K.lib()
+    spec, indptr, indices, feats, E = device_graph(K, synth, "papers100M")
+    dev = indptr.device
+    B, fan, world, rank = 7998, [25, 10, 5], 2, 1
+    k = B // 3
+    tr = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
+    L.legion_synth_seed_ids(None, tr.data_ptr(), 0, spec.n_train, spec.V, spec.M2, spec.C2, 1, 0)
+    torch.cuda.synchronize()
+    mask = (tr % world) == rank
+    srcs, triple_no = tr[mask].contiguous(), torch.nonzero(mask).reshape(-1).contiguous()
+    n_tr = int(srcs.numel())
+    seeds = torch.empty((n_tr + k - 1) // k * B, dtype=torch.int32, device=dev)
+    L.legion_synth_lp_seeds(None, seeds.data_ptr(), srcs.data_ptr(), triple_no.data_ptr(), n_tr, B, indptr.data_ptr(), indices.data_ptr(), spec.V, 1)
+    torch.cuda.synchronize()
+    K.check()
+    assert n_tr > 5_000_000
+    lab = torch.empty(spec.V, dtype=torch.int32, device=dev)
+    L.legion_synth_labels(None, lab.data_ptr(), 0, spec.V, spec.classes)
+    my_lab = lab[seeds.long()].contiguous()
+    n = int(seeds.numel())
+    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), spec.V, spec.F,
+                   dict(train=[((seeds.data_ptr(), n), (my_lab.data_ptr(), n))]), B, fan, E=E)
+    eng.alloc_features()
+    rs = np.random.RandomState(5)
+    h_seeds = seeds.cpu().numpy()
+    # the same rule in numpy on the first and the last batch (closed form of the generator: no graph needed on the host)
+    m31 = 2147483647
+    for b in (0, n // B - 1):
+        j = np.arange(b * k, min((b + 1) * k, n_tr))
+        t = triple_no[torch.from_numpy(j).to(dev)].cpu().numpy()
+        s = srcs[torch.from_numpy(j).to(dev)].cpu().numpy().astype(np.int64)
+        x1 = synth.minstd_pow(np.uint64(1) + np.uint64(2) * t.astype(np.uint64) + np.uint64(1))
+        x2 = (x1 * np.uint64(48271)) % np.uint64(m31)
+        st = torch.from_numpy(s).to(dev)
+        lo = indptr[st].cpu().numpy()
+        deg = indptr[st + 1].cpu().numpy() - lo
+        pick = lo + ((x1 - np.uint64(1)) % np.maximum(deg, 1).astype(np.uint64)).astype(np.int64)
+        pos = np.where(deg > 0, indices[torch.from_numpy(pick).to(dev)].cpu().numpy(), s)
+        neg = ((x2 - np.uint64(1)) % np.uint64(spec.V)).astype(np.int64)
+        batch = h_seeds[b * B:(b + 1) * B]
+        m = len(j)
+        assert np.array_equal(batch[:m], s) and np.array_equal(batch[k:k + m], pos) and np.array_equal(batch[2 * k:2 * k + m], neg)
+        assert (s % world == rank).all()
+    dup_batches = 0
+    for it in (0, 3, n // B - 1):
+        eng.run_batch(0, it)
+        res = eng.result(0)
+        batch = h_seeds[it * B:(it + 1) * B]
+        dup_batches += int(len(np.unique(batch)) < B)
+        check_batch(res, spec, synth, B, fan, indptr, indices, batch, rs, distinct_seeds=False)
+    assert dup_batches > 0          # hot positives repeat inside a batch: the duplicate-seed path really ran
+    eng.close()

@@ -276,6 +276,13 @@ int32_t GPUCache_ShardChunkRows(const GPUCache* c, int32_t dev_id);
 float* GPUCache_GetShardChunk(const GPUCache* c, int32_t dev_id, int32_t chunk);
 int GPUCache_ExportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, void* handle64);
 int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, const void* handle64);
+/* "Feature Cache Hit" metric (GPUCache.cu:130-147,414-425: feature_cache_hit every 500th batch, printed at the last level).
+ * Every $LEGION_CACHE_HIT_PERIOD-th batch (default 500) the FindFeat pass of the cached gathers counts its hits into pinned,
+ * device-mapped words; "<dev> Feature Cache Hit: <ratio>" is printed when the next sampling starts (no blocking copy).
+ * GPUCache_HitSampling is what the gather launchers call; GPUCache_FeatureCacheHitRate returns the newest completed
+ * sample (hits / rows, -1 if none; synchronises the device). */
+int32_t* GPUCache_HitSampling(GPUCache* c, int32_t dev_id, int last_launch_of_batch, int first_launch_of_batch);
+double GPUCache_FeatureCacheHitRate(GPUCache* c, int32_t dev_id, int32_t* hits_out, int32_t* rows_out);
 uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id);
 uint64_t* GPUCache_GetEdgeAccessedMap(const GPUCache* c, int32_t dev_id);
 /* ranked candidate lists of clique Ki (device pointers on the clique's first GPU): QF / QT */
@@ -416,6 +423,10 @@ void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int3
 void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, int32_t V, uint32_t M2, uint32_t C2, int32_t stride, int32_t phase);
 /* streaming-copy kernel used by bench.py to report the measured HBM peak */
 void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes);
+/* the same copy with an explicit variant (profiles/copy_sweep.py): 256-thread workgroups, `unroll` 16-byte chunks in
+ * flight per lane (1, 2, 4, 8), nt bit 0 = non-temporal stores, bit 1 = non-temporal loads, contig = block-strided;
+ * grid <= 0: one iteration per lane.  Returns 0, or -1 for an unknown variant. */
+int legion_copy_f4_cfg(void* stream, void* dst, const void* src, int64_t bytes, int32_t grid, int32_t unroll, int32_t nt, int32_t contig);
 
 /* ---- self-description for tests ------------------------------------------------------------ */
 /* RNG probe: k[i] = sample index for (idx[i], deg[i]) computed ON THE GPU with the kernel's

@@ -146,6 +146,8 @@ _SIGS = {
     "GPUCache_GetShardChunk": (vp, [vp, i32, i32]),
     "GPUCache_ExportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
     "GPUCache_ImportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
+    "GPUCache_HitSampling": (vp, [vp, i32, C.c_int, C.c_int]),
+    "GPUCache_FeatureCacheHitRate": (f64, [vp, i32, vp, vp]),
     "GPUCache_GetNodeAccessedMap": (vp, [vp, i32]),
     "GPUCache_GetEdgeAccessedMap": (vp, [vp, i32]),
     "GPUCache_GetFeatureMap": (vp, [vp, i32]),
@@ -201,6 +203,7 @@ _SIGS = {
     "legion_synth_labels": (None, [vp, vp, i32, i32, i32]),
     "legion_synth_seed_ids": (None, [vp, vp, i64, i64, i32, u32, u32, i32, i32]),
     "legion_copy_f4": (None, [vp, vp, vp, i64]),
+    "legion_copy_f4_cfg": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, i32]),
     "legion_rng_probe": (None, [vp, vp, vp, vp, i32]),
 }
 

@@ -80,6 +80,12 @@ void GPUCache_InitializeCacheController(GPUCache* c, int32_t dev_id, int32_t tot
     HIP_CHECK(hipMalloc(&k->d_max_ids, sizeof(int32_t)));
     HIP_CHECK(hipMemset(k->d_max_ids, 0, sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&k->d_global_count, sizeof(int32_t)));
+    HIP_CHECK(hipHostMalloc((void**)&k->hit_stats, 4 * sizeof(int32_t), hipHostMallocMapped));
+    if (k->hit_stats) {
+        memset(k->hit_stats, 0, 4 * sizeof(int32_t));
+        HIP_CHECK(hipHostGetDevicePointer((void**)&k->hit_stats_dev, k->hit_stats, 0));
+    }
+    k->find_iter = 0; k->hit_samples = 0; k->last_hit_rate = -1.0;
     k->iter = 0;
     k->max_ids = 0;
     HIP_CHECK(hipDeviceSynchronize());
@@ -131,10 +137,55 @@ void GPUCache_Finalize(GPUCache* c, int32_t dev_id)
     if (k->edge_access_time) (void)hipFree(k->edge_access_time);
     if (k->d_max_ids) (void)hipFree(k->d_max_ids);
     if (k->d_global_count) (void)hipFree(k->d_global_count);
+    if (k->hit_stats) { (void)hipHostFree(k->hit_stats); k->hit_stats = nullptr; k->hit_stats_dev = nullptr; }
     k->node_access_time = k->edge_access_time = nullptr;
     k->d_max_ids = k->d_global_count = nullptr;
     free_shard(c, dev_id);
     if (c->d_shard_tab[dev_id]) { (void)hipFree(c->d_shard_tab[dev_id]); c->d_shard_tab[dev_id] = nullptr; }
+}
+
+// "Feature Cache Hit" (GPUCache.cu:414-425): every $LEGION_CACHE_HIT_PERIOD-th batch (default 500, the reference's
+// find_iter_ % 500) the lookup passes of the batch count their hits.  Called by the gather launchers with
+// first / last = this is the first / last gather launch of the batch; returns the device pointer the lookup pass adds
+// {hits, rows} to, or null when the batch is not sampled.  The ratio of sampling k - 1 is printed when sampling k starts
+// (the reference prints after a blocking copy; here nothing waits for the GPU).
+int32_t* GPUCache_HitSampling(GPUCache* c, int32_t dev_id, int last_launch_of_batch, int first_launch_of_batch)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count) return nullptr;
+    CacheController* k = c->ctl[dev_id];
+    if (!k->hit_stats_dev) return nullptr;
+    const char* e = getenv("LEGION_CACHE_HIT_PERIOD");
+    const int period = e && atoi(e) > 0 ? atoi(e) : 500;
+    const bool sampled = k->find_iter % period == 0;
+    int32_t* out = nullptr;
+    if (sampled) {
+        const int slot = k->hit_samples & 1;
+        if (first_launch_of_batch) {
+            int32_t* prev = k->hit_stats + 2 * (slot ^ 1);
+            if (k->hit_samples > 0 && prev[1] > 0) {
+                k->last_hit_rate = (double)prev[0] / (double)prev[1];
+                std::cout << dev_id << " Feature Cache Hit: " << k->last_hit_rate << std::endl;
+            }
+            k->hit_stats[2 * slot] = 0; k->hit_stats[2 * slot + 1] = 0;   // last written two samplings ago
+        }
+        out = k->hit_stats_dev + 2 * slot;
+    }
+    if (last_launch_of_batch) {
+        if (sampled) k->hit_samples++;
+        k->find_iter++;
+    }
+    return out;
+}
+// the newest completed sample (synchronises the device): hits / rows of the last sampled batch, or -1 if there is none
+double GPUCache_FeatureCacheHitRate(GPUCache* c, int32_t dev_id, int32_t* hits_out, int32_t* rows_out)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count || !c->ctl[dev_id]->hit_stats || c->ctl[dev_id]->hit_samples == 0) return -1.0;
+    CacheController* k = c->ctl[dev_id];
+    { DeviceGuard guard(dev_id); HIP_CHECK(hipDeviceSynchronize()); }
+    const int32_t* s = k->hit_stats + 2 * ((k->hit_samples - 1) & 1);
+    if (hits_out) *hits_out = s[0];
+    if (rows_out) *rows_out = s[1];
+    return s[1] > 0 ? (double)s[0] / (double)s[1] : -1.0;
 }
 
 int32_t GPUCache_NodeCapacity(const GPUCache* c, int32_t dev_id)

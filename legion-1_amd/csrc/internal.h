@@ -151,6 +151,7 @@ struct GatherArgs {
     int32_t off_idx, size_idx;                // nc[] indices of (offset, size); off_idx < 0 => offset 0
     int32_t dst_rows;                         // capacity of dst in rows (<= 0: unbounded)
     int32_t* rows_seen;                       // host-mapped word: the launch leaves its actual row count here (may be null)
+    int32_t* hit_stats;                       // host-mapped {hits, rows}: the lookup pass of a SAMPLED batch adds its counts (may be null)
     int32_t rows_hint;                        // row count of an earlier launch of this kind (0: unknown)
     bool table_on_host;                       // the backing table is pinned host memory (misses cross PCIe)
 };
@@ -281,8 +282,14 @@ struct CacheController {              // PreSCCacheController, GPUCache.cu:239-5
     int8_t* topo_owner = nullptr;     // edge_index_map_: id -> owner logical GPU | -1
     int32_t* topo_row = nullptr;      // edge_offset_map_: id -> row in owner's fragment | -1
     int32_t* d_global_count = nullptr;
+    // Feature-cache hit rate (GPUCache.cu:130-147,414-425: counted every 500th batch, printed at the last level).
+    // Two pinned, device-mapped {hits, rows} slots: sampling k counts into slot k % 2 while the host prints what
+    // sampling k - 1 left in the other one -- no device-to-host copy, no synchronisation.
     int32_t find_iter = 0;
-    int64_t h_cache_hit = 0;
+    int32_t* hit_stats = nullptr;      // host view, 2 x {hits, rows}
+    int32_t* hit_stats_dev = nullptr;  // device view
+    int32_t hit_samples = 0;           // samplings started
+    double last_hit_rate = -1.0;       // what the last print showed
 };
 
 struct GPUCache {

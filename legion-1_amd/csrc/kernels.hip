@@ -653,7 +653,15 @@ __global__ __launch_bounds__(kBlock) void k_row_ptrs(GatherKArgs a)
             }
             g.row_ptr[r] = src;
         }
+        if (g.hit_stats) { // feature_cache_hit (GPUCache.cu:130-147): one atomic per wave and step
+            int32_t h = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) h += (r0 + u * stride < rows && gidx[u] >= 0) ? 1 : 0;
+            for (int o = 32; o > 0; o >>= 1) h += __shfl_down(h, o);
+            if (lane_id() == 0 && h) atomicAdd(g.hit_stats, h);
+        }
     }
+    if (g.hit_stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(g.hit_stats + 1, rows);
 }
 
 template <typename VT, int UNROLL, int NT>
@@ -979,6 +987,8 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
         HIP_CHECK_LAST();
     }
     if (g.rows_hint > 0) {
+        // (re-swept in round 2, profiles/r02_gather_grid_sweep.md: 1-4 iterations per lane and a 3-25 % margin all land
+        // within the run-to-run spread of 323-342 us at the papers100M shape)
         const int64_t est = std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024);
         grid = grid_for(est * C, kBlock * (g.table_on_host ? 1 : 3), 8192); // rows over PCIe: latency-bound, maximise lanes in flight
     } else {

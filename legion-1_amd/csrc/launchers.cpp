@@ -167,6 +167,7 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     g.size_idx = size_idx;
     g.dst_rows = p->feature_rows;
     g.rows_seen = nullptr; g.rows_hint = 0;
+    g.hit_stats = nullptr;
     if (p->rows_seen && p->rows_seen_dev) { // slot: level of a per-level gather, or the last one for "all rows of the batch"
         const int slot = off_idx < 0 ? LEGION_MAX_HOPS + 1 : (off_idx - 3) / 2;
         g.rows_hint = *(volatile int32_t*)(p->rows_seen + slot);
@@ -181,6 +182,9 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
         g.chunk_shift = cache->chunk_shift[Ki];
         g.nchunks = cache->nchunks[Ki];
         g.row_ptr = p->row_ptr; // FindFeat + source selection as their own pass over the rows (k_row_ptrs)
+        // the last gather of a batch: level `hops` of the per-level gathers, or the one gather over all rows
+        // (a recorded batch graph would bake the decision in: graphs never sample)
+        if (!p->capturing) g.hit_stats = GPUCache_HitSampling(cache, dev_id, off_idx < 0 || off_idx == 3 + 2 * p->hops, off_idx < 0 || off_idx == 3);
     }
     if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return; }
     launch_gather((hipStream_t)strm_hdl, g, rows_bound);

@@ -2,6 +2,7 @@
 // (same closed forms, integer only, so host/numpy and device outputs are bit identical), and
 // the streaming copy used by bench.py to report the measured HBM peak.
 #include "internal.h"
+#include <algorithm>
 
 namespace legion {
 
@@ -100,20 +101,27 @@ __global__ void k_synth_lp_seeds(int32_t* out, const int32_t* srcs, const int64_
 }
 
 typedef float copy_v4f __attribute__((ext_vector_type(4)));
-// streaming copy: 4 independent 16-byte non-temporal loads in flight per lane, non-temporal stores
+// Streaming copy, the measured HBM ceiling bench.py prints beside the vendor peak.  U independent 16-byte loads in
+// flight per lane; NT bit 0: non-temporal stores, bit 1: non-temporal loads.  CONTIG: a workgroup copies one
+// contiguous block of U * blockDim chunks per step (block-strided) instead of striding every load by the whole grid.
+template <int U, int NT, bool CONTIG>
 __global__ __launch_bounds__(256) void k_copy_f4(copy_v4f* __restrict__ dst, const copy_v4f* __restrict__ src, int64_t n)
 {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        copy_v4f a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        copy_v4f c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    const int64_t step = CONTIG ? (int64_t)blockDim.x : (int64_t)gridDim.x * blockDim.x;    // distance between a lane's U chunks
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * U;                              // distance between iterations
+    int64_t i = CONTIG ? (int64_t)blockIdx.x * blockDim.x * U + threadIdx.x : threadIdx.x + (int64_t)blockDim.x * blockIdx.x;
+    for (; i < n; i += stride) {
+        copy_v4f v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (i + u * step < n) v[u] = (NT & 2) ? __builtin_nontemporal_load(src + i + u * step) : src[i + u * step];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (i + u * step < n) {
+                if (NT & 1) __builtin_nontemporal_store(v[u], dst + i + u * step);
+                else dst[i + u * step] = v[u];
+            }
     }
-    for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 } // namespace legion
@@ -176,13 +184,29 @@ void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, in
     k_synth_seed_ids<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(out, i0, n, (uint32_t)V, M2, C2, stride, phase);
     HIP_CHECK_LAST();
 }
-void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes)
+// variant: unroll in {1,2,4,8}, nt in 0..3, contig 0/1; grid <= 0: one iteration per lane
+int legion_copy_f4_cfg(void* stream, void* dst, const void* src, int64_t bytes, int32_t grid, int32_t unroll, int32_t nt, int32_t contig)
 {
     const int64_t n = bytes / 16;
-    if (n <= 0) return;
-    // 32 k workgroups measured fastest on MI355X (5.3 TB/s for 2 x 4 GiB; 2048: 4.7, torch copy_: 4.8)
-    k_copy_f4<<<32768, 256, 0, (hipStream_t)stream>>>((copy_v4f*)dst, (const copy_v4f*)src, n);
-    HIP_CHECK_LAST();
+    if (n <= 0) return 0;
+    if (grid <= 0) grid = (int32_t)std::min<int64_t>((n + 256ll * unroll - 1) / (256ll * unroll), 0x7FFFFFFF);
+    hipStream_t s = (hipStream_t)stream;
+    copy_v4f* d = (copy_v4f*)dst;
+    const copy_v4f* r = (const copy_v4f*)src;
+#define LEGION_COPY_CASE(U, N, C) if (unroll == U && nt == N && contig == C) { k_copy_f4<U, N, (C != 0)><<<grid, 256, 0, s>>>(d, r, n); HIP_CHECK_LAST(); return 0; }
+#define LEGION_COPY_NT(U, C) LEGION_COPY_CASE(U, 0, C) LEGION_COPY_CASE(U, 1, C) LEGION_COPY_CASE(U, 2, C) LEGION_COPY_CASE(U, 3, C)
+    LEGION_COPY_NT(1, 0) LEGION_COPY_NT(2, 0) LEGION_COPY_NT(4, 0) LEGION_COPY_NT(8, 0)
+    LEGION_COPY_NT(1, 1) LEGION_COPY_NT(2, 1) LEGION_COPY_NT(4, 1) LEGION_COPY_NT(8, 1)
+#undef LEGION_COPY_NT
+#undef LEGION_COPY_CASE
+    LEGION_ARG_ERROR("legion_copy_f4_cfg: no such variant");
+    return -1;
+}
+void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes)
+{
+    // fastest variant of profiles/copy_sweep.py on MI355X (profiles/r02_copy_sweep.md): one 16-byte chunk per lane, no
+    // loop (bytes / 4096 workgroups), non-temporal loads and stores: 6.52-6.56 TB/s; round 1's 32768 x 4 chunks: 5.3
+    (void)legion_copy_f4_cfg(stream, dst, src, bytes, 0, 1, 3, 0);
 }
 
 } // extern "C"

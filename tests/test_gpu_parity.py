@@ -350,14 +350,20 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
             for b in (d_in, d_nc, d_out, d_pi, d_po):
                 b.free()
     # steady state through the unified cache (local + peer shards + backing-table misses)
+    monkeypatch.setenv("LEGION_CACHE_HIT_PERIOD", "1")        # the reference samples every 500th batch (GPUCache.cu:414)
     for g in range(G):
         for it in (0, 1):
             for m_mode, ids in ((0, parts[g]),):
                 ref = orcs[g].run_batch(ids, ds.labels[ids], it, mode=m_mode)
-                eng.run_batch(g, it, mode=m_mode)
+                eng.run_batch(g, it, mode=m_mode, per_level=(it == 0))
                 got = eng.result(g)
                 assert_batch_equal(ref, got)
                 hit = orcs[g].node_map[got["ids"]] >= 0
+                # "Feature Cache Hit" counter of the lookup pass (feature_cache_hit, GPUCache.cu:130-147)
+                n_hit, n_rows = C.c_int32(0), C.c_int32(0)
+                rate = L.GPUCache_FeatureCacheHitRate(eng.cache, g, C.byref(n_hit), C.byref(n_rows))
+                if L.GPUCache_NodeCapacity(eng.cache, g) > 0:
+                    assert (n_hit.value, n_rows.value) == (int(hit.sum()), len(hit)) and abs(rate - hit.mean()) < 1e-12
                 # hits and misses both occur, unless the clique-wide cache (capacity x Kg) already holds nearly every node
                 assert 0 < hit.sum() and (hit.sum() < len(hit) or L.GPUCache_NodeCapacity(eng.cache, g) * Kg > 0.9 * V)
     eng.close()

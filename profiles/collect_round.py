@@ -47,7 +47,7 @@ rf = d["roofline"]
 
 out = ["# %s: kernel table + bench line, papers100M shape\n" % tag,
        "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --headline-only --cpu-baseline-seconds 0`",
-       "(batch 8000, fan-out 25,10,5; 5 warm-up + 50 timed batches of the serial schedule; MI355X)\n",
+       "(batch 8000, fan-out 25,10,5; 5 warm-up + 50 census batches + R windows of 50 timed batches of the serial schedule; MI355X)\n",
        "profiled run: %.4f ms/batch, k_gather avg %.2f us by HIP events;" % (profiled["ms_per_step"], profiled["roofline"]["avg_launch_us"]),
        "un-profiled default run (`%s_bench_line.json`): %.4f ms/batch, k_gather %.1f us = %.0f GB/s = %.3f of 8 TB/s, whole batch %.3f, %.2f G edges/s, %.0f GB/s of rows;" % (
            tag, d["ms_per_step"], rf["avg_launch_us"], rf["achieved"], rf["frac"], rf["pipeline_frac"], d["value"] / 1e9, d["feature_GBps"]),
@@ -65,3 +65,8 @@ open(os.path.join(ROOT, "profiles", tag + "_bench_papers100M_summary.md"), "w").
 r = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "make_pmc_traffic.py"), tag], cwd=ROOT, capture_output=True, text=True)
 print(r.stdout[-600:], r.stderr[-300:])
 print("\n".join(out[3:6]))
+
+# gpurun only merges gpurun_out/ back: leave copies of everything written to profiles/ there
+for f in glob.glob(os.path.join(ROOT, "profiles", tag + "_*")):
+    shutil.copy(f, scratch)
+print("copies of profiles/%s_* in %s" % (tag, scratch))

@@ -24,7 +24,7 @@ bench = None
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, counter)
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-           "--steps", "10", "--warmup", "2", "--headline-only", "--cpu-baseline-seconds", "0"]
+           "--steps", "10", "--warmup", "2", "--min-time", "0", "--headline-only", "--cpu-baseline-seconds", "0"]
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         sys.exit(r.stdout[-2000:] + r.stderr[-2000:])
@@ -38,7 +38,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     for k, v in vals.items():
         per[k]["launches"] = len(v)
         per[k][counter + "_KiB_avg"] = round(sum(v) / len(v), 1)
-batches = 12
+batches = next(v["launches"] for k, v in per.items() if k.startswith("k_seed"))   # warm-up + census + one timed window
 g = next(k for k in per if k.startswith("k_gather"))
 read = per[g]["FETCH_SIZE_KiB_avg"] * 1024 * 2
 write = per[g]["WRITE_SIZE_KiB_avg"] * 1024
@@ -46,7 +46,7 @@ alg = bench["gather_algorithmic_bytes_per_batch"]
 samp = sum((v.get("FETCH_SIZE_KiB_avg", 0) + v.get("WRITE_SIZE_KiB_avg", 0)) * 1024 * v["launches"] for k, v in per.items()
            if not k.startswith("k_gather")) / batches
 doc = {
-    "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --headline-only --cpu-baseline-seconds 0  (one pass per counter: FETCH_SIZE, WRITE_SIZE; profiles/make_pmc_traffic.py)",
+    "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --min-time 0 --headline-only --cpu-baseline-seconds 0  (one pass per counter: FETCH_SIZE, WRITE_SIZE; profiles/make_pmc_traffic.py)",
     "workload": bench["config"]["workload"],
     "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; gfx950 correction: FETCH_SIZE x2 for the 16 B/lane reads of k_gather; sampler kernels raw",
     "kernels": per,

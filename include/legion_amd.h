@@ -259,13 +259,16 @@ void GPUCache_SetPreSc(GPUCache* c, int is_presc);
 void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph);
 int32_t GPUCache_MaxIdNum(const GPUCache* c, int32_t dev_id);
 float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);
-/* HIP-IPC size limit.  No single allocation larger than $LEGION_IPC_MAX_BYTES (default 1.5 GiB) is exported or
- * imported: on this pool's dmabuf-only IPC hipIpcOpenMemHandle never returned for single allocations of 3.6 GB and
- * 7.1 GB while 1.78 GB opened at once (profiles/r01_unified_ipc_notes.md).  The Export / Import calls and the trainer hand-off
- * buffers (IPCEnv_Initialize*Buffer) refuse larger ones with a sticky error (LEGION_ERR_EXIT: the server exits
- * non-zero instead of leaving a trainer stalled in ipc_service.initialize()).  Shards and fragments are therefore
- * lists of <= $LEGION_SHARD_CHUNK_BYTES (default 1 GiB) chunks. */
-#define LEGION_IPC_MAX_BYTES_DEFAULT 1610612736ll /* 1.5 GiB */
+/* HIP-IPC size limit.  No single allocation of more than $LEGION_IPC_MAX_BYTES (default 2^31 - 2 MiB) is exported or
+ * imported.  Cause (profiles/r02_ipc_limit.md): inside a PyTorch process the HIP runtime is the one bundled with the torch
+ * wheel (ROCm 7.0.51831 for torch 2.10.0+rocm7.0 -- also for every library loaded later, liblegion_amd.so and the
+ * ipc_service extension included), and its hipIpcOpenMemHandle never returns for an allocation of 2^31 bytes or more
+ * (2^31 - 2 MiB opens in 0.2 ms, 2^31 hangs); the system runtime (ROCm 7.2, what the standalone `legion` binary links)
+ * opens 8 GiB under 240 GiB of memory pressure without trouble.  Trainers are PyTorch processes, so the limit binds every
+ * hand-off buffer.  The Export / Import calls and IPCEnv_Initialize*Buffer refuse larger allocations with a sticky error
+ * (LEGION_ERR_EXIT: the server exits non-zero instead of leaving a trainer stalled in ipc_service.initialize()).  Shards
+ * and fragments are lists of <= $LEGION_SHARD_CHUNK_BYTES (default 1 GiB) chunks and are not affected. */
+#define LEGION_IPC_MAX_BYTES_DEFAULT 2145386496ll /* 2^31 - 2 MiB: the largest size verified with the torch-bundled runtime */
 /* HIP-IPC exchange of a clique member's feature shard (64-byte handle); returns 0 on success */
 int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64);
 int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle64);

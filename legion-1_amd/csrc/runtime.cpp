@@ -32,10 +32,9 @@ void report_error(const char* file, int line, const char* msg, bool hip_failure)
 bool error_pending() { return !t_last_error.empty(); }
 bool error_is_fatal() { return g_error_mode == LEGION_ERR_EXIT; }
 
-// Largest single allocation that may cross a process boundary as a HIP IPC handle.  On this pool (dmabuf-only IPC,
-// HSA_ENABLE_IPC_MODE_LEGACY=0) hipIpcOpenMemHandle never returned for one allocation of 3.6 GB and of 7.1 GB, while
-// 1.78 GB (and every <= 1 GiB chunk since) opened at once (profiles/r01_unified_ipc_notes.md).  The threshold sits
-// somewhere in between (2 GiB is the obvious suspect); 1.5 GiB is below everything that is known to work.
+// Largest single allocation that may cross a process boundary as a HIP IPC handle: see LEGION_IPC_MAX_BYTES_DEFAULT in
+// include/legion_amd.h (the HIP runtime bundled with the torch wheel, ROCm 7.0, hangs in hipIpcOpenMemHandle at >= 2^31
+// bytes; profiles/r02_ipc_limit.md).
 int64_t ipc_max_bytes()
 {
     const char* e = getenv("LEGION_IPC_MAX_BYTES");

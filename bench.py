@@ -53,6 +53,7 @@ def parse(argv=None):
                     help="headline leg.  replicated: every GPU holds all features (Kg=1).  unified: the clique-wide "
                          "hotness-partitioned feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
     ap.add_argument("--no-unified-leg", action="store_true", help="N > 1: skip the unified-cache leg that follows the replicated headline")
+    ap.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the owner-computes exchange variant of the unified-cache gather")
     ap.add_argument("--unified-timeout", type=float, default=420.0,
                     help="N > 1: seconds the unified-cache leg may take before the headline line is printed without it")
     ap.add_argument("--table", default="device", choices=["device", "host"],
@@ -302,7 +303,9 @@ def guarded_unified_leg(c, line):
     the headline without it and every rank leaves."""
     def fire():
         if c.rank == 0:
-            line["unified_cache"] = {"error": f"did not finish within {c.args.unified_timeout:.0f} s"}
+            msg = f"did not finish within {c.args.unified_timeout:.0f} s"
+            part = getattr(c, "partial_unified", None)
+            line["unified_cache"] = dict(part, exchange_variant={"error": msg}) if part else {"error": msg}
             print(json.dumps(line), flush=True)
         os._exit(0 if c.rank == 0 else 3)
     timer = threading.Timer(c.args.unified_timeout, fire)
@@ -509,7 +512,7 @@ def run_leg(c, unified, headline):
     leg = dict(unified=unified, cache_info=cache_info, elapsed=elapsed_max, windows=[round(w * 1e3, 4) for w in win_max],
                job_edges=job_edges, job_nodes=job_nodes, job_bytes=job_bytes, samp_bytes=samp_bytes, gather_bytes=gather_bytes,
                u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, graph=None,
-               xgmi=None)
+               xgmi=None, exchange=None)
 
     # the other schedule on the very same K batches (reported beside the headline, never instead of it)
     if headline and not per_level and not intra and not args.headline_only:
@@ -547,11 +550,65 @@ def run_leg(c, unified, headline):
 
     if unified and not per_level:
         leg["xgmi"] = unified_cache_traffic(c, eng, me, cache_info, float(leg["g_ms"].mean()))
+    if unified and not headline and world > 1 and not args.no_exchange_leg:
+        c.partial_unified = unified_summary(c, leg)      # what the watchdog prints if the exchange leg never comes back
+        try:
+            leg["exchange"] = exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes)
+        except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
+            leg["exchange"] = {"error": repr(ex)[:300]}
     D.barrier(world)   # nobody unmaps a cache shard while a peer may still read it
     drain()
     eng.close()
     log.free()
     return leg
+
+
+def exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes):
+    """The same K batches with the owner-computes exchange gather (legion-1_amd/exchange.py) instead of in-kernel peer loads:
+    per batch one all-to-all of request lists and one of rows over RCCL.  Lock-step and host-synchronous (the split sizes of the
+    all-to-all are read back every batch), so this is one timed window of K steps."""
+    import torch
+    from legion1_amd.exchange import ExchangeGather
+    args, K, D, L = c.args, c.K, c.D, c.L
+    world, dev, B, fan, H, F = c.world, c.dev, c.B, c.fan, c.H, c.spec.F
+    xg = ExchangeGather(K, eng, me, world, F, dev, eng.num_ids)
+    K_steps, W = args.steps, args.warmup
+    t_x = [0.0]
+
+    def step(i):
+        L.GPUMemoryPool_SetCurrentPipe(pool, 0)
+        L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, i % steps_avail, me, me, K.TRAINMODE)
+        for h in range(H):
+            L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
+        t0 = time.perf_counter()
+        info = xg.run(stream, pool)
+        t_x[0] += time.perf_counter() - t0
+        return info
+
+    for i in range(min(W, 2)):
+        step(i)
+    torch.cuda.synchronize()
+    D.barrier(world)
+    t_x[0] = 0.0
+    t0 = time.perf_counter()
+    for i in range(K_steps):
+        info = step(W + i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    D.barrier(world)
+    el_max, (rows_req, x_s) = D.aggregate(el, [info["rows_requested"], t_x[0]], world, device=dev)
+    xg.close()
+    out = {"what": "owner-computes exchange: request lists and rows over one RCCL all-to-all each per batch, owners gather from their own HBM",
+           "ms_per_step": round(el_max / K_steps * 1e3, 4), "value": round(job_edges / el_max, 1), "unit": "edges/s",
+           "feature_GBps": round(job_nodes * 4 * F / el_max / 1e9, 2), "exchange_ms_per_step": round(x_s / world / K_steps * 1e3, 4),
+           "rows_requested_last_batch_per_gpu": round(rows_req / world, 1)}
+    rate = rows_req / world * 4 * F / max(x_s / world / K_steps, 1e-9) / 1e9     # rows received per GPU / time inside the exchange
+    if c.shared_device:
+        out["a2a_rows_GBps_same_device"] = round(rate, 1)
+    else:
+        out.update({"xgmi_recv_GBps_per_gpu": round(rate, 1), "xgmi_frac_of_peak": round(rate / XGMI_PEAK_GBPS, 4)})
+    return out
 
 
 def roofline_of(c, leg):
@@ -647,7 +704,7 @@ def unified_summary(c, leg):
             "feature_GBps": round(leg["job_nodes"] * 4 * F / el / 1e9, 2),
             "gather_avg_launch_us": round(float(g.mean()) * 1e3, 2) if len(g) else None,
             "gather_frac_of_hbm_peak": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
-            "windows": len(leg["windows"]), **(leg["cache_info"] or {}), **(leg["xgmi"] or {})}
+            "windows": len(leg["windows"]), **(leg["cache_info"] or {}), **(leg["xgmi"] or {}), "exchange_variant": leg["exchange"]}
 
 
 def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):

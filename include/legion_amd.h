@@ -313,6 +313,17 @@ void update_cache(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMem
  * get_feature_kernel for op 1,3,..,2H+1; used when the per-level overlap is not wanted. */
 void get_feature_kernel_all(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool,
                             int32_t dev_id, int in_memory);
+/* Owner-computes exchange variant of the feature gather (SURVEY 5 option b; the reference reads peer caches in-kernel over
+ * NVLink, Kernels.cu:662-702 -- this is the collective formulation for one process per GPU, the all-to-all itself is RCCL /
+ * hipMemcpyPeer in the caller: legion-1_amd/exchange.py).  plan (requester): rows of the batch cached on another clique member are
+ * listed per owner -- req_row[k] = row in the owner's shard, req_dst[k] = row of the batch, contiguous per owner, owner-major,
+ * counts[j] = rows asked of clique member j (device int32[2 * LEGION_MAX_DEVICE], the second half is scratch) -- and every other
+ * row (own shard, backing table) is gathered at once.  serve (owner): rows list[0..n) of this GPU's shard -> out[n x F].
+ * scatter (requester): rows[k] -> feature row req_dst[k] of the current pipe.  All pointers are device pointers. */
+int legion_exchange_plan(void* stream, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id,
+                         int32_t* req_row, int32_t* req_dst, int32_t* counts);
+void legion_exchange_serve(void* stream, GPUCache* cache, int32_t dev_id, const int32_t* list, int32_t n, float* out);
+void legion_exchange_scatter(void* stream, GPUMemoryPool* memorypool, const float* rows, const int32_t* req_dst, int32_t n, int32_t F);
 
 /* ---- Operator plugin API: src/Operator.h:4-27 ------------------------------------------- */
 typedef struct OpParams {

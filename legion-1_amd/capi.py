@@ -161,6 +161,9 @@ _SIGS = {
     "GPU_Random_Sampling": (None, [vp, vp, vp, vp, i32, i32, C.c_int]),
     "get_feature_kernel": (None, [vp, vp, vp, vp, i32, i32, C.c_int]),
     "get_feature_kernel_all": (None, [vp, vp, vp, vp, i32, C.c_int]),
+    "legion_exchange_plan": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp]),
+    "legion_exchange_serve": (None, [vp, vp, i32, vp, i32, vp]),
+    "legion_exchange_scatter": (None, [vp, vp, vp, vp, i32, i32]),
     "make_update_plan": (None, [vp, vp, vp, vp, i32, i32]),
     "update_cache": (None, [vp, vp, vp, vp, i32, i32]),
     "NewBatchGenerator": (vp, [C.c_int]), "NewRandomSampler": (vp, [C.c_int]), "NewFeatureExtractor": (vp, [C.c_int]),

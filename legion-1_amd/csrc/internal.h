@@ -154,8 +154,14 @@ struct GatherArgs {
     int32_t* hit_stats;                       // host-mapped {hits, rows}: the lookup pass of a SAMPLED batch adds its counts (may be null)
     int32_t rows_hint;                        // row count of an earlier launch of this kind (0: unknown)
     bool table_on_host;                       // the backing table is pinned host memory (misses cross PCIe)
+    bool row_ptr_ready;                       // row_ptr was filled by the caller (exchange plan): skip the lookup pass
 };
 void launch_gather(hipStream_t s, const GatherArgs& a, int32_t rows_bound);
+// owner-computes exchange variant of the gather (kernels.hip "S5, owner-computes"): counts = int32[2 * kMaxParts] scratch
+void launch_exchange_plan(hipStream_t s, const GatherArgs& g, int32_t me, int32_t Kg, int32_t* slot, int32_t* counts,
+                          int32_t* req_row, int32_t* req_dst, int32_t rows_bound);
+void launch_exchange_rows(hipStream_t s, bool scatter, const float* const* shard_chunks, int32_t chunk_shift, const int32_t* list,
+                          int32_t n, int32_t F, const float* in, float* out, int32_t out_rows);
 void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_t hops, unsigned long long* access,
                     int32_t* max_ids, int32_t bound);
 void launch_rng_probe(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* k, int32_t n);

@@ -710,6 +710,114 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// S5, owner-computes exchange variant (SURVEY 5 option b; one process per GPU): rows whose cache slot lives on another
+// clique member are not read in-kernel over xGMI; the requester lists them per owner, the owners gather them from their
+// own HBM and the rows come back in one all-to-all (RCCL / hipMemcpyPeer).  Everything else is gathered as usual.
+// ------------------------------------------------------------------------------------------------
+struct ExchArgs {
+    GatherArgs g;
+    FastDiv div_cap;
+    int32_t me;               // this GPU's index inside its clique
+    int32_t Kg;
+    int32_t* slot;            // scratch [rows]: FindFeat result of the count pass
+    int32_t* counts;          // [Kg]: rows requested from each clique member (me: 0)
+    int32_t* cursor;          // [Kg]: fill cursors (zeroed by the count pass)
+    int32_t* req_row;         // out, grouped by owner: row inside the owner's shard
+    int32_t* req_dst;         // out, same order: destination row of the batch
+};
+// pass 1: FindFeat (GPUCache.cu:387-400) per row + rows per owner.  One LDS histogram per workgroup, Kg atomics per workgroup.
+__global__ __launch_bounds__(kBlock) void k_exch_count(ExchArgs a)
+{
+    __shared__ int32_t s_cnt[kMaxParts];
+    const GatherArgs& g = a.g;
+    const int32_t rows = g.nc[g.size_idx];
+    if (threadIdx.x < kMaxParts) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int32_t r = threadIdx.x + blockDim.x * blockIdx.x; r < rows; r += gridDim.x * blockDim.x) {
+        const int32_t id = g.sampled_ids[r];
+        const int32_t gidx = (id >= 0 && g.feat_map) ? g.feat_map[id] : -1;
+        a.slot[r] = gidx;
+        if (gidx >= 0) {
+            const int32_t owner = (int32_t)fdiv((uint32_t)gidx, a.div_cap);
+            if (owner != a.me) atomicAdd(&s_cnt[owner], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.Kg && s_cnt[threadIdx.x]) atomicAdd(a.counts + threadIdx.x, s_cnt[threadIdx.x]);
+}
+// pass 2: the request lists (contiguous per owner, owner-major) and the source address of every row that is served
+// locally (own shard / backing table); rows owned by a peer get no address: the local gather skips them.
+__global__ __launch_bounds__(kBlock) void k_exch_fill(ExchArgs a)
+{
+    __shared__ int32_t s_cnt[kMaxParts], s_base[kMaxParts];
+    const GatherArgs& g = a.g;
+    const int32_t rows = g.nc[g.size_idx];
+    const int32_t per_wg = (rows + gridDim.x - 1) / gridDim.x;
+    const int32_t r0 = blockIdx.x * per_wg, r1 = min(r0 + per_wg, rows);
+    if (threadIdx.x < kMaxParts) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int32_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
+        const int32_t gidx = a.slot[r];
+        if (gidx >= 0) {
+            const int32_t owner = (int32_t)fdiv((uint32_t)gidx, a.div_cap);
+            if (owner != a.me) atomicAdd(&s_cnt[owner], 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < a.Kg) {
+        int32_t off = 0;                                   // lists are owner-major: offset of owner j = sum of counts before it
+        for (int j = 0; j < (int)threadIdx.x; j++) off += a.counts[j];
+        s_base[threadIdx.x] = off + (s_cnt[threadIdx.x] ? atomicAdd(a.cursor + threadIdx.x, s_cnt[threadIdx.x]) : 0);
+        s_cnt[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int32_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
+        const int32_t gidx = a.slot[r];
+        const int32_t id = g.sampled_ids[r];
+        const float* src = nullptr;
+        if (gidx >= 0) {
+            const uint32_t owner = fdiv((uint32_t)gidx, a.div_cap);
+            const uint32_t fidx = (uint32_t)gidx - owner * (uint32_t)g.cache_capacity;
+            if ((int32_t)owner == a.me) {
+                const float* chunk = g.shard_tab[owner * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
+                src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * g.F;
+            } else {
+                const int32_t k = s_base[owner] + atomicAdd(&s_cnt[owner], 1);
+                a.req_row[k] = (int32_t)fidx;
+                a.req_dst[k] = r;
+            }
+        } else if (id >= 0 && g.table) {
+            src = g.table + (int64_t)(id % g.total_num_nodes) * g.F;
+        }
+        g.row_ptr[r] = src;
+    }
+}
+// owner side: rows list[0..n) of this GPU's shard -> out[n x F]; requester side: rows[k] -> dst[req_dst[k]]
+template <typename VT, bool SCATTER>
+__global__ __launch_bounds__(kBlock) void k_exch_rows(const float* const* __restrict__ shard_chunks, int32_t chunk_shift,
+                                                      const int32_t* __restrict__ list, int32_t n, int32_t F,
+                                                      const float* __restrict__ in, float* __restrict__ out, FastDiv div_c,
+                                                      int32_t out_rows)
+{
+    constexpr int VEC = sizeof(VT) / 4;
+    const int32_t C = F / VEC;
+    const int64_t total = (int64_t)n * C, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += stride) {
+        const uint32_t k = fdiv((uint32_t)q, div_c), ch = (uint32_t)q - k * (uint32_t)C;
+        const int32_t row = list[k];
+        if (SCATTER) {
+            if (out_rows > 0 && row >= out_rows) continue; // never write past the buffer
+            const VT v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(in + (int64_t)k * F) + ch);
+            __builtin_nontemporal_store(v, reinterpret_cast<VT*>(out + (int64_t)row * F) + ch);
+        } else {
+            const float* src = shard_chunks[row >> chunk_shift] + (int64_t)(row & ((1 << chunk_shift) - 1)) * F;
+            const VT v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(src) + ch);
+            __builtin_nontemporal_store(v, reinterpret_cast<VT*>(out + (int64_t)k * F) + ch);
+        }
+    }
+}
+
 // S7: HotnessMeasure (GPUCache.cu:227-235)
 __global__ __launch_bounds__(kBlock) void k_hotness(const int32_t* __restrict__ ids, const int32_t* __restrict__ nc,
                                                     int32_t hops, unsigned long long* __restrict__ access,
@@ -981,7 +1089,7 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // bound is typically filled 15-60 %, so the grid is sized from the row count an earlier launch of this kind
     // reported (rows_seen, no host round trip), + 25 %; without a report: the bound, at most 512 workgroups per CU.
     int grid;
-    if (g.row_ptr) {
+    if (g.row_ptr && !g.row_ptr_ready) {
         const int64_t est_rows = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
         k_row_ptrs<<<grid_for(est_rows, kBlock * 4, 64), kBlock, 0, s>>>(a);
         HIP_CHECK_LAST();
@@ -996,6 +1104,42 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     }
     if (vec4) k_gather<v4f, 1, 2><<<grid, kBlock, 0, s>>>(a);
     else k_gather<float, 1, 2><<<grid, kBlock, 0, s>>>(a);
+    HIP_CHECK_LAST();
+}
+
+void launch_exchange_plan(hipStream_t s, const GatherArgs& g, int32_t me, int32_t Kg, int32_t* slot, int32_t* counts,
+                          int32_t* req_row, int32_t* req_dst, int32_t rows_bound)
+{
+    if (rows_bound <= 0) return;
+    ExchArgs a;
+    a.g = g;
+    a.div_cap = FastDiv((uint32_t)(g.cache_capacity > 0 ? g.cache_capacity : 1));
+    a.me = me; a.Kg = Kg; a.slot = slot; a.counts = counts; a.cursor = counts + kMaxParts;
+    a.req_row = req_row; a.req_dst = req_dst;
+    HIP_CHECK(hipMemsetAsync(counts, 0, 2 * kMaxParts * sizeof(int32_t), s));
+    const int64_t est = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
+    const int grid = grid_for(est, kBlock * 4, 64);
+    k_exch_count<<<grid, kBlock, 0, s>>>(a);
+    HIP_CHECK_LAST();
+    k_exch_fill<<<grid, kBlock, 0, s>>>(a);
+    HIP_CHECK_LAST();
+}
+void launch_exchange_rows(hipStream_t s, bool scatter, const float* const* shard_chunks, int32_t chunk_shift, const int32_t* list,
+                          int32_t n, int32_t F, const float* in, float* out, int32_t out_rows)
+{
+    if (n <= 0 || F <= 0) return;
+    const bool vec4 = (F % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
+    const int C = vec4 ? F / 4 : F;
+    if ((int64_t)n * C >= (1ll << 31)) { LEGION_ARG_ERROR("legion_exchange: rows*F exceeds 2^31 work items"); return; }
+    const FastDiv dc((uint32_t)C);
+    const int grid = grid_for((int64_t)n * C, kBlock * 2, 8192);
+    if (scatter) {
+        if (vec4) k_exch_rows<v4f, true><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
+        else k_exch_rows<float, true><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
+    } else {
+        if (vec4) k_exch_rows<v4f, false><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
+        else k_exch_rows<float, false><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
+    }
     HIP_CHECK_LAST();
 }
 

@@ -144,19 +144,18 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     p->bound_nodes += (int32_t)slots;
 }
 
-static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* p, int32_t dev_id,
-                          int off_idx, int size_idx, int32_t rows_bound)
+// Arguments of a gather over the rows (nc[off_idx], nc[size_idx]) of the current pipe; false (sticky error) if it cannot run.
+static bool gather_args(GatherArgs& g, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* p, int32_t dev_id, int off_idx, int size_idx)
 {
     const int32_t F = noder->float_attr_len;
     if (F < 0) std::cout << "error feature len\n"; // Kernels.cu:719-721
     const int q = p->current_pipe;
-    if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return; }
-    GatherArgs g;
+    if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return false; }
     g.table = (dev_id >= 0 && dev_id < noder->partition_count && noder->replica_attrs[dev_id]) ? noder->replica_attrs[dev_id] : noder->float_attrs;
     g.table_on_host = g.table == noder->float_attrs && noder->features_location != LEGION_LOC_DEVICE;
     g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1;
     g.feat_map = nullptr;
-    g.row_ptr = nullptr;
+    g.row_ptr = nullptr; g.row_ptr_ready = false;
     g.cache_capacity = 1;
     g.F = F;
     g.total_num_nodes = noder->total_num_nodes;
@@ -186,8 +185,15 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
         // (a recorded batch graph would bake the decision in: graphs never sample)
         if (!p->capturing) g.hit_stats = GPUCache_HitSampling(cache, dev_id, off_idx < 0 || off_idx == 3 + 2 * p->hops, off_idx < 0 || off_idx == 3);
     }
-    if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return; }
-    launch_gather((hipStream_t)strm_hdl, g, rows_bound);
+    if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return false; }
+    return true;
+}
+
+static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* p, int32_t dev_id,
+                          int off_idx, int size_idx, int32_t rows_bound)
+{
+    GatherArgs g;
+    if (gather_args(g, cache, noder, p, dev_id, off_idx, size_idx)) launch_gather((hipStream_t)strm_hdl, g, rows_bound);
 }
 
 // get_feature_kernel, Kernels.cu:706-748.  op_id 2l+1 gathers level l.
@@ -207,6 +213,41 @@ void get_feature_kernel_all(void* strm_hdl, GPUCache* cache, GPUNodeStorage* nod
     if (!noder || !pool_ready(memorypool, "get_feature_kernel_all")) return;
     if (!in_memory) return;
     gather_common(strm_hdl, cache, noder, memorypool, dev_id, -1, 0, memorypool->num_ids); // rows [0, nc[0])
+}
+
+// ---- owner-computes exchange variant of the gather (SURVEY 5 option b), one process per GPU ---------------------------------
+// Step 1 on the requester.  Rows [0, nc[0]) of the batch: those cached on ANOTHER clique member are listed (req_row: row in the
+// owner's shard, req_dst: row of the batch; contiguous per owner, owner-major; counts[j] rows for clique member j); all other rows
+// (own shard, backing table) are gathered into the feature buffer right away.  counts: device int32[2 * LEGION_MAX_DEVICE].
+int legion_exchange_plan(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id,
+                         int32_t* req_row, int32_t* req_dst, int32_t* counts)
+{
+    if (!noder || !cache || !req_row || !req_dst || !counts || !pool_ready(memorypool, "legion_exchange_plan")) return -1;
+    GPUMemoryPool* p = memorypool;
+    GatherArgs g;
+    if (!gather_args(g, cache, noder, p, dev_id, -1, 0)) return -1;
+    if (!g.feat_map || !g.row_ptr || !p->cache_search_buffer) { LEGION_ARG_ERROR("legion_exchange_plan: needs a filled unified cache"); return -1; }
+    launch_exchange_plan((hipStream_t)strm_hdl, g, dev_id % cache->Kg, cache->Kg, p->cache_search_buffer, counts, req_row, req_dst, p->num_ids);
+    g.row_ptr_ready = true;   // k_exch_fill resolved the local rows (and left the peers' rows without a source)
+    g.hit_stats = nullptr;
+    launch_gather((hipStream_t)strm_hdl, g, p->num_ids);
+    return error_pending() ? -1 : 0;
+}
+// Step 2 on the owner: rows list[0..n) of THIS GPU's shard -> out[n x F] (a contiguous send buffer).
+void legion_exchange_serve(void* strm_hdl, GPUCache* cache, int32_t dev_id, const int32_t* list, int32_t n, float* out)
+{
+    if (!cache || dev_id < 0 || dev_id >= cache->device_count || !cache->d_shard_tab[dev_id] || (n > 0 && (!list || !out))) { LEGION_ARG_ERROR("legion_exchange_serve: bad arguments"); return; }
+    const int Ki = dev_id / cache->Kg, j = dev_id % cache->Kg;
+    launch_exchange_rows((hipStream_t)strm_hdl, false, cache->d_shard_tab[dev_id] + (size_t)j * cache->nchunks[Ki], cache->chunk_shift[Ki], list, n,
+                         cache->float_attr_len, nullptr, out, 0);
+}
+// Step 3 on the requester: rows[k] (as the owners returned them, in request order) -> feature row req_dst[k] of the current pipe.
+void legion_exchange_scatter(void* strm_hdl, GPUMemoryPool* memorypool, const float* rows, const int32_t* req_dst, int32_t n, int32_t F)
+{
+    if (!pool_ready(memorypool, "legion_exchange_scatter")) return;
+    float* dst = memorypool->float_features[memorypool->current_pipe];
+    if (!dst || (n > 0 && (!rows || !req_dst))) { LEGION_ARG_ERROR("legion_exchange_scatter: bad arguments"); return; }
+    launch_exchange_rows((hipStream_t)strm_hdl, true, nullptr, 0, req_dst, n, F, rows, dst, memorypool->feature_rows);
 }
 
 // make_update_plan, Kernels.cu:758-783

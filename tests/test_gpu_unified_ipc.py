@@ -95,6 +95,27 @@ def _worker(rank, world, port, q):
             peer_rows += int(((slot >= 0) & (slot // cap != rank)).sum())
             assert ((slot >= 0) & (slot // cap == rank)).any() and (slot < 0).any()
         assert peer_rows > 0
+        # the owner-computes exchange variant of the same gather (legion1_amd/exchange.py: plan -> all-to-all of the request
+        # lists -> every owner gathers from its own shard -> all-to-all of the rows -> scatter): bit-identical batches
+        import torch
+        from legion1_amd.exchange import ExchangeGather
+        xg = ExchangeGather(K, eng, rank, world, F, torch.device("cuda", 0), eng.num_ids)
+        exchanged = 0
+        for it in range(min(2, (len(parts[rank]) + B - 1) // B)):
+            ref = me.run_batch(parts[rank], ds.labels[parts[rank]], it)
+            eng.run_batch(rank, it, gather=False, plan=False)                        # sampler only
+            feat = eng.out[rank][0]["feat"]
+            L.d_memset_async(feat.ptr, 0xFF, feat.nbytes, None)                      # poison: every row must be rewritten
+            L.d_stream_sync(None)
+            info = xg.run(None, eng.pools[rank])
+            got = eng.result(rank)
+            assert_batch_equal(ref, got)
+            slot = me.node_map[got["ids"]]
+            assert info["rows_requested"] == int(((slot >= 0) & (slot // cap != rank)).sum()) > 0
+            assert info["per_owner"][rank] == 0 and sum(info["per_owner"]) == info["rows_requested"]
+            exchanged += info["rows_served"]
+        assert exchanged > 0
+        xg.close()
         dist.barrier()        # nobody unmaps a shard while the peer may still read it
         eng.close()
         dist.barrier()

@@ -46,10 +46,19 @@ def _worker(rank, world, port, q):
     D.barrier(world)
     elapsed = 1.0 + rank                     # synthetic clock: the MAX over ranks must win
     emax, (e_sum, n_sum) = D.aggregate(elapsed, [edges, nodes], world)
+    # bench.py's timing: per window the MAX over ranks (every rank runs the same windows)
+    wins = D.aggregate_max_vec([0.5 + rank, 2.0 - rank, 1.0], world)
+    assert wins == [1.5, 2.0, 1.0]
+    # link-prediction lists: triples dealt by src % world, thirds kept, pos/neg from the triple's GLOBAL stream position
+    lp = S.lp_trainingset(ds, 600, 30, rank=rank, world=world)
+    k = 10
+    lp3 = lp.reshape(-1, 3, k)
+    assert (lp3[:, 0, :] % world == rank).all()
+    everyone = D.allgather_object(lp3.transpose(0, 2, 1).reshape(-1, 3).tolist(), world)
     # torch tensors shard the same way as numpy arrays
     t_mine = D.shard_seeds(torch.from_numpy(ds.train), rank, world)
     assert np.array_equal(t_mine.numpy(), mine)
-    q.put((rank, steps, edges, nodes, emax, e_sum, n_sum, mine.tolist()))
+    q.put((rank, steps, edges, nodes, emax, e_sum, n_sum, mine.tolist(), everyone))
     dist.destroy_process_group()
 
 
@@ -64,7 +73,7 @@ def test_two_rank_sharding_and_aggregation():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, s0, e0, n0, emax0, es0, ns0, ids0), (r1, s1, e1, n1, emax1, es1, ns1, ids1) = out
+    (r0, s0, e0, n0, emax0, es0, ns0, ids0, lp0), (r1, s1, e1, n1, emax1, es1, ns1, ids1, lp1) = out
     assert s0 == s1 > 0
     assert emax0 == emax1 == 2.0                      # max over ranks
     assert es0 == es1 == e0 + e1 and ns0 == ns1 == n0 + n1   # whole-job totals
@@ -75,3 +84,8 @@ def test_two_rank_sharding_and_aggregation():
     import legion1_amd.dist as D
     rate, ms = D.throughput_line(es0, emax0, s0)
     assert rate == es0 / 2.0 and ms == 2.0 / s0 * 1e3
+    # the two per-GPU link-prediction lists together hold exactly the triples of the 1-GPU list (padding repeats aside)
+    assert lp0 == lp1
+    one = S.lp_trainingset(ds, 600, 30).reshape(-1, 3, 10).transpose(0, 2, 1).reshape(-1, 3)
+    got = {tuple(t) for part in lp0 for t in part}
+    assert {tuple(t) for t in one.tolist()} == got

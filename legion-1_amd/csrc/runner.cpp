@@ -197,7 +197,11 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
                 }
                 g = GPUMemoryPool_EndBatchCapture(r->memorypool, r->streams[0]);
             }
-            if (!g) { LEGION_ARG_ERROR("Runner_RunOnce: recording the batch graph failed"); return; }
+            if (!g) {
+                LEGION_ARG_ERROR("Runner_RunOnce: recording the batch graph failed");
+                if (error_is_fatal()) exit(EXIT_FAILURE);   // never leave the trainer waiting for a batch that will not come
+                return;
+            }
         }
         LegionBatchGraph_Launch(g, r->streams[0], IPCEnv_GetLocalBatchId(env, batch_id));
         if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[0]));

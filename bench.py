@@ -470,6 +470,9 @@ def run_leg(c, unified, headline):
         D.barrier(world)
         return el
 
+    xc = None
+    if unified and rank == 0 and world > 1:
+        import legion1_amd.xgmi_counters as xc
     for i in range(W):
         step(i)
     # census (untimed): the K batches of the timed windows once with their counters logged -- what the windows produce
@@ -479,6 +482,7 @@ def run_leg(c, unified, headline):
     drain()
     census[0] = False
     g_ms = []                      # HIP-event time of every timed gather launch (its own stream)
+    x0, t_x0 = (xc.read(), time.perf_counter()) if xc else (None, 0.0)
     windows = [window()]
     if not per_level:
         g_ms += [L.d_event_elapsed_ms(a, b) for a, b in ev]
@@ -490,6 +494,7 @@ def run_leg(c, unified, headline):
         if not per_level:
             g_ms += [L.d_event_elapsed_ms(a, b) for a, b in ev]
     K.check()
+    xgmi_hw = xc.rate(x0, xc.read(), time.perf_counter() - t_x0, world) if xc else None
 
     counters = log.to_numpy(np.int32, (K_steps + W) * 32).reshape(K_steps + W, 2, 16)[W:]
     edges = counters[:, 1, 2 + H].astype(np.int64)          # ec[2+H]: cumulative edges of the batch
@@ -512,7 +517,7 @@ def run_leg(c, unified, headline):
     leg = dict(unified=unified, cache_info=cache_info, elapsed=elapsed_max, windows=[round(w * 1e3, 4) for w in win_max],
                job_edges=job_edges, job_nodes=job_nodes, job_bytes=job_bytes, samp_bytes=samp_bytes, gather_bytes=gather_bytes,
                u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, graph=None,
-               xgmi=None, exchange=None)
+               xgmi=None, exchange=None, xgmi_hw=xgmi_hw)
 
     # the other schedule on the very same K batches (reported beside the headline, never instead of it)
     if headline and not per_level and not intra and not args.headline_only:
@@ -591,18 +596,23 @@ def exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes):
     torch.cuda.synchronize()
     D.barrier(world)
     t_x[0] = 0.0
+    xc = None
+    if c.rank == 0:
+        import legion1_amd.xgmi_counters as xc
+    x0 = xc.read() if xc else None
     t0 = time.perf_counter()
     for i in range(K_steps):
         info = step(W + i)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    hw = xc.rate(x0, xc.read(), el, world) if xc else None
     D.barrier(world)
     el_max, (rows_req, x_s) = D.aggregate(el, [info["rows_requested"], t_x[0]], world, device=dev)
     xg.close()
     out = {"what": "owner-computes exchange: request lists and rows over one RCCL all-to-all each per batch, owners gather from their own HBM",
            "ms_per_step": round(el_max / K_steps * 1e3, 4), "value": round(job_edges / el_max, 1), "unit": "edges/s",
            "feature_GBps": round(job_nodes * 4 * F / el_max / 1e9, 2), "exchange_ms_per_step": round(x_s / world / K_steps * 1e3, 4),
-           "rows_requested_last_batch_per_gpu": round(rows_req / world, 1)}
+           "rows_requested_last_batch_per_gpu": round(rows_req / world, 1), "xgmi_hw_counters": hw}
     rate = rows_req / world * 4 * F / max(x_s / world / K_steps, 1e-9) / 1e9     # rows received per GPU / time inside the exchange
     if c.shared_device:
         out["a2a_rows_GBps_same_device"] = round(rate, 1)
@@ -704,7 +714,8 @@ def unified_summary(c, leg):
             "feature_GBps": round(leg["job_nodes"] * 4 * F / el / 1e9, 2),
             "gather_avg_launch_us": round(float(g.mean()) * 1e3, 2) if len(g) else None,
             "gather_frac_of_hbm_peak": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
-            "windows": len(leg["windows"]), **(leg["cache_info"] or {}), **(leg["xgmi"] or {}), "exchange_variant": leg["exchange"]}
+            "windows": len(leg["windows"]), **(leg["cache_info"] or {}), **(leg["xgmi"] or {}), "xgmi_hw_counters": leg["xgmi_hw"],
+            "exchange_variant": leg["exchange"]}
 
 
 def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):

@@ -319,7 +319,10 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // computable by ANY workgroup of k_write -- which is what lets k_write resolve the edges that lost their claim
 // itself (round 1 needed a fourth launch per hop, k_resolve, for that).
 constexpr int32_t kWinBase = 0x40000000;
-constexpr int kWriteEntries = 12288;    // k_write keeps <= 52 KB of tile prefix in LDS (one entry per tile up to 12.6 M slots per hop) // loser states are -2 - slot with slot < 2^30; winners sit below them
+// k_write keeps <= 26 KB of tile prefix in LDS: one entry per tile up to 6.3 M slots per hop, per 2 tiles up to 12.6 M, ...
+// Swept on MI355X (profiles/r02_write_lds_sweep.md): 12288 entries (one per tile at the 10 M-slot bound of a {25,10,5} hop 3,
+// 42 KB, 3 workgroups per CU) 19.7 us avg / 108 us at the products shape; 6144 (pairs of tiles, 22 KB, 6 per CU) 17.9 / 91; 3072: 18.6; 1536: 19.0 / 116
+constexpr int kWriteEntries = 6144; // loser states are -2 - slot with slot < 2^30; winners sit below them
 __device__ inline int32_t enc_win(int32_t r) { return -2 - (kWinBase + r); }
 __device__ inline bool is_win(int32_t v) { return v <= -2 - kWinBase; }
 __device__ inline int32_t win_rank(int32_t v) { return -2 - v - kWinBase; }
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
     // its own tiles AND (nodes) for the tile of any winner one of its losing edges points at -- no scan launch, no
     // inter-workgroup hand-off (device-scope fences cost an L2 write-back + invalidate per XCD: profiles/r01_gather_sweep.md).
     // Layout: one entry per group of 2^gshift tiles (gshift == 0 unless the hop's static bound exceeds kWriteEntries
-    // tiles), groups in blocks of kPB = 2^lpb: s_tile[g] = (edges | nodes << 16) in front of group g INSIDE its block
+    // tiles: occupancy beats granularity, see kWriteEntries), groups in blocks of kPB = 2^lpb: s_tile[g] = (edges | nodes << 16) in front of group g INSIDE its block
     // (both < 2^16: kPB * 2^gshift <= 64 tiles of <= 1024), s_blk[b] = (edges, nodes) in front of block b.
     extern __shared__ uint32_t s_tile[];
     int2* const s_blk = reinterpret_cast<int2*>(s_tile + a.lds_entries);

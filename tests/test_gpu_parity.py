@@ -763,3 +763,20 @@ def test_lp_seed_generator_matches_numpy(K, synth, small_ds, world):
         for b in (d_s, d_t, d_o):
             b.free()
     d_ip.free(); d_ix.free()
+
+
+def test_full_batch_bound_on_a_small_graph(K, oracle, synth):
+    """B = 8000 with fan-out {25,10,5} sizes hop 3 for 10 M slots = 9 766 tiles: k_write's LDS tile prefix then holds one
+    entry per PAIR of tiles (kWriteEntries = 6144, gshift = 1) -- the layout every full-size run uses.  On a 98 k-node graph
+    the oracle still finishes in seconds, so that path is compared bit for bit (the other oracle tests all have gshift = 0)."""
+    ds = synth.generate(synth.spec_for("products", scale=0.04))
+    B, fan = 8000, [25, 10, 5]
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan)
+    assert len(ds.train) < B                       # one short batch: 7 864 seeds, -1 padding never sampled
+    ref = orc.run_batch(ds.train, ds.labels[ds.train], 0)
+    assert ref["ec"][5] > 2_000_000                # several thousand tiles in hop 3
+    for _ in range(2):
+        eng.run_batch(0, 0, per_level=False)
+        assert_batch_equal(ref, eng.result(0))
+    eng.close()

@@ -141,7 +141,7 @@ def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0
     codes = [p.returncode for p in procs]
     if any(codes):
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-        return next(c for c in codes if c) or 1
+        return next((c for c in codes if c and c > 0), 1)      # a rank's own exit code; 1 if only stragglers were stopped
     return 0
 
 

@@ -265,9 +265,14 @@ float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);
  * ipc_service extension included), and its hipIpcOpenMemHandle never returns for an allocation of 2^31 bytes or more
  * (2^31 - 2 MiB opens in 0.2 ms, 2^31 hangs); the system runtime (ROCm 7.2, what the standalone `legion` binary links)
  * opens 8 GiB under 240 GiB of memory pressure without trouble.  Trainers are PyTorch processes, so the limit binds every
- * hand-off buffer.  The Export / Import calls and IPCEnv_Initialize*Buffer refuse larger allocations with a sticky error
- * (LEGION_ERR_EXIT: the server exits non-zero instead of leaving a trainer stalled in ipc_service.initialize()).  Shards
- * and fragments are lists of <= $LEGION_SHARD_CHUNK_BYTES (default 1 GiB) chunks and are not affected. */
+ * hand-off buffer.  The Export / Import calls and IPCEnv_InitializeSamplesBuffer refuse larger allocations with a sticky
+ * error (LEGION_ERR_EXIT: the server exits non-zero instead of leaving a trainer stalled in ipc_service.initialize()).
+ * Shards and fragments are lists of <= $LEGION_SHARD_CHUNK_BYTES (default 1 GiB) chunks and are not affected.
+ * The FEATURE hand-off buffer (rows x F x 4 bytes per pipe -- the one that does outgrow the limit, 8.6 GB at the uk-union 3-hop
+ * shape) is then built from <= $LEGION_HANDOFF_CHUNK_BYTES (default 1 GiB) physical chunks (HIP virtual memory management),
+ * exported as POSIX file descriptors over an abstract unix socket and mapped back to back into one virtual range by
+ * legion_ipc_client_open, so the trainer still sees one contiguous tensor; its 64-byte handle slot in the shm table carries
+ * a descriptor ("LGNVMM01", total, chunk, count) instead of an IPC handle.  $LEGION_HANDOFF_VMM=1 forces that path. */
 #define LEGION_IPC_MAX_BYTES_DEFAULT 2145386496ll /* 2^31 - 2 MiB: the largest size verified with the torch-bundled runtime */
 /* HIP-IPC exchange of a clique member's feature shard (64-byte handle); returns 0 on success */
 int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64);

@@ -14,9 +14,16 @@
 #include <ctime>
 #include <fcntl.h>
 #include <iostream>
+#include <algorithm>
+#include <atomic>
+#include <vector>
+#include <poll.h>
 #include <semaphore.h>
 #include <sys/mman.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/un.h>
+#include <thread>
 #include <unistd.h>
 
 using namespace legion;
@@ -60,6 +67,157 @@ static void* shm_map(size_t sz, int* fd_out)
     return addr;
 }
 
+// ---- hand-off buffers above the HIP-IPC size limit -------------------------------------------------------------------
+// hipIpcOpenMemHandle of the runtime bundled with the torch wheel (ROCm 7.0) never returns for an allocation of 2^31 bytes or
+// more (profiles/r02_ipc_limit.md), and a trainer needs its feature rows as ONE contiguous tensor.  Such a buffer is therefore
+// built from <= 1 GiB physical chunks (HIP virtual memory management), exported as POSIX file descriptors and handed to the
+// trainer over an abstract unix socket (SCM_RIGHTS); the trainer maps the chunks back to back into one reserved virtual range
+// (profiles/vmm_ipc_probe.*: 5 GiB mapped in 21 ms under ROCm 7.2, 3 GiB in 0.3 ms inside a PyTorch process).  The 64-byte
+// handle slot of the shm table carries a descriptor instead of an IPC handle.
+struct VmmDesc {               // lives in shmStruct::memHandle[dev][pipe][1]
+    char magic[8];             // "LGNVMM01"
+    uint64_t total, chunk;     // bytes mapped, bytes per chunk (the last one may be shorter)
+    uint32_t nchunks, pad;
+};
+static_assert(sizeof(VmmDesc) <= sizeof(hipIpcMemHandle_t), "descriptor must fit the handle slot");
+static const char kVmmMagic[8] = {'L', 'G', 'N', 'V', 'M', 'M', '0', '1'};
+
+static socklen_t vmm_sock_addr(sockaddr_un* a, int dev, int pipe)
+{
+    memset(a, 0, sizeof(*a));
+    a->sun_family = AF_UNIX;
+    const std::string name = ipc_ns() + "legion_vmm_" + std::to_string(dev) + "_" + std::to_string(pipe);
+    const size_t n = std::min(name.size(), sizeof(a->sun_path) - 2);
+    memcpy(a->sun_path + 1, name.data(), n);       // abstract namespace: sun_path[0] == 0, nothing to unlink
+    return (socklen_t)(offsetof(sockaddr_un, sun_path) + 1 + n);
+}
+static bool send_fd(int sock, int fd)
+{
+    char byte = 'f';
+    iovec io{&byte, 1};
+    alignas(cmsghdr) char ctrl[CMSG_SPACE(sizeof(int))] = {0};
+    msghdr msg{};
+    msg.msg_iov = &io; msg.msg_iovlen = 1; msg.msg_control = ctrl; msg.msg_controllen = sizeof(ctrl);
+    cmsghdr* c = CMSG_FIRSTHDR(&msg);
+    c->cmsg_level = SOL_SOCKET; c->cmsg_type = SCM_RIGHTS; c->cmsg_len = CMSG_LEN(sizeof(int));
+    memcpy(CMSG_DATA(c), &fd, sizeof(int));
+    return sendmsg(sock, &msg, MSG_NOSIGNAL) == 1;
+}
+static int recv_fd(int sock)
+{
+    char byte;
+    iovec io{&byte, 1};
+    alignas(cmsghdr) char ctrl[CMSG_SPACE(sizeof(int))] = {0};
+    msghdr msg{};
+    msg.msg_iov = &io; msg.msg_iovlen = 1; msg.msg_control = ctrl; msg.msg_controllen = sizeof(ctrl);
+    if (recvmsg(sock, &msg, 0) != 1) return -1;
+    cmsghdr* c = CMSG_FIRSTHDR(&msg);
+    int fd = -1;
+    if (c && c->cmsg_level == SOL_SOCKET && c->cmsg_type == SCM_RIGHTS) memcpy(&fd, CMSG_DATA(c), sizeof(int));
+    return fd;
+}
+
+struct VmmRegion {             // server side: one mapped, exported buffer + the thread that serves its descriptors
+    void* va = nullptr;
+    VmmDesc desc{};
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<int> fds;
+    int listen_fd = -1, device = 0;
+    std::thread server;
+    std::atomic<bool> stop{false};
+};
+static void vmm_serve(VmmRegion* r)
+{
+    while (!r->stop.load()) {
+        pollfd p{r->listen_fd, POLLIN, 0};
+        if (poll(&p, 1, 200) <= 0) continue;
+        const int s = accept(r->listen_fd, nullptr, nullptr);
+        if (s < 0) continue;
+        bool ok = send(s, &r->desc, sizeof(r->desc), MSG_NOSIGNAL) == (ssize_t)sizeof(r->desc);
+        for (size_t i = 0; ok && i < r->fds.size(); i++) ok = send_fd(s, r->fds[i]);
+        char ack;
+        if (ok) (void)!recv(s, &ack, 1, 0);        // the trainer closes after it has mapped everything
+        close(s);
+    }
+}
+static void vmm_release(VmmRegion* r)
+{
+    r->stop.store(true);
+    if (r->server.joinable()) r->server.join();
+    if (r->listen_fd >= 0) close(r->listen_fd);
+    for (int fd : r->fds) close(fd);
+    if (r->va) {
+        (void)hipMemUnmap(r->va, r->desc.total);
+        for (auto h : r->handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(r->va, r->desc.total);
+    }
+    delete r;
+}
+// nullptr (sticky error) when the platform cannot do it
+static VmmRegion* vmm_create(int logical_dev, int pipe, size_t bytes)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = physical_device(logical_dev);
+    prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) {
+        (void)hipGetLastError();
+        LEGION_ARG_ERROR("hand-off buffer above the HIP-IPC limit: this runtime has no virtual memory management");
+        return nullptr;
+    }
+    const char* e = getenv("LEGION_HANDOFF_CHUNK_BYTES");
+    size_t chunk = e && atoll(e) > 0 ? (size_t)atoll(e) : ((size_t)1 << 30);
+    chunk = std::max(gran, chunk / gran * gran);
+    VmmRegion* r = new VmmRegion();
+    r->device = logical_dev;
+    const size_t total = (bytes + gran - 1) / gran * gran;
+    memcpy(r->desc.magic, kVmmMagic, 8);
+    r->desc.total = total; r->desc.chunk = chunk; r->desc.nchunks = (uint32_t)((total + chunk - 1) / chunk);
+    bool ok = hipMemAddressReserve(&r->va, total, 0, nullptr, 0) == hipSuccess;
+    for (uint32_t c = 0; ok && c < r->desc.nchunks; c++) {
+        const size_t sz = std::min(chunk, total - (size_t)c * chunk);
+        hipMemGenericAllocationHandle_t h;
+        ok = hipMemCreate(&h, sz, &prop, 0) == hipSuccess;
+        if (!ok) break;
+        r->handles.push_back(h);
+        ok = hipMemMap((char*)r->va + (size_t)c * chunk, sz, 0, h, 0) == hipSuccess;
+        int fd = -1;
+        ok = ok && hipMemExportToShareableHandle(&fd, h, hipMemHandleTypePosixFileDescriptor, 0) == hipSuccess;
+        if (ok) r->fds.push_back(fd);
+    }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = ok && hipMemSetAccess(r->va, total, &acc, 1) == hipSuccess;
+    if (ok) {
+        sockaddr_un addr;
+        const socklen_t len = vmm_sock_addr(&addr, logical_dev, pipe);
+        r->listen_fd = socket(AF_UNIX, SOCK_STREAM, 0);
+        ok = r->listen_fd >= 0 && bind(r->listen_fd, (sockaddr*)&addr, len) == 0 && listen(r->listen_fd, 8) == 0;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        LEGION_ARG_ERROR("hand-off buffer above the HIP-IPC limit: building the chunked (virtual memory) buffer failed");
+        r->desc.total = r->va ? total : 0;
+        vmm_release(r);
+        return nullptr;
+    }
+    r->server = std::thread(vmm_serve, r);
+    return r;
+}
+// osHandle: the ROCm 7.0 runtime (torch wheel) dereferences it as int*, ROCm 7.2 takes the descriptor by value (like CUDA).
+// By pointer first: 7.2 then sees a huge, unopened descriptor number and fails cleanly; by value first would crash 7.0.
+static hipError_t vmm_import_fd(hipMemGenericAllocationHandle_t* h, int fd)
+{
+    static int fd_cell;        // static storage: the low 32 bits of its address are never a small (open) descriptor number
+    fd_cell = fd;
+    hipError_t r = hipMemImportFromShareableHandle(h, (void*)&fd_cell, hipMemHandleTypePosixFileDescriptor);
+    if (r == hipSuccess) return r;
+    (void)hipGetLastError();
+    return hipMemImportFromShareableHandle(h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
+}
+
 struct IPCEnv {
     volatile shmStruct* shm = nullptr;
     int shm_fd = -1;
@@ -69,6 +227,7 @@ struct IPCEnv {
     int32_t raw_batch_size = 0;
     std::vector<int32_t> train_batch_size, valid_batch_size, test_batch_size;
     int32_t train_step = 0, valid_step = 0, test_step = 0, epoch = 0, pipeline_depth = LEGION_PIPELINE_DEPTH;
+    std::vector<VmmRegion*> vmm;   // feature buffers above the HIP-IPC size limit (chunked, mapped, served over a unix socket)
 };
 
 extern "C" {
@@ -188,9 +347,25 @@ void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_
     (void)batch_size;
     if (!e || device_id < 0 || device_id >= e->device_count) { LEGION_ARG_ERROR("InitializeFeaturesBuffer: bad arguments"); return; }
     DeviceGuard guard(device_id);
+    const size_t bytes = (size_t)num_ids * feature_dim * sizeof(float);
+    const char* force = getenv("LEGION_HANDOFF_VMM");
+    const bool vmm = (int64_t)bytes > ipc_max_bytes() || (force && force[0] == '1');
     for (int32_t i = 0; i < pipeline_depth; i++) {
-        void* p = ipc_alloc(e->shm, device_id, i, 1, (size_t)num_ids * feature_dim * sizeof(float));
-        if (!p) return;   // refused (size limit) or out of memory: the error is sticky, nothing is registered
+        void* p = nullptr;
+        if (vmm) {   // too large for one IPC handle under the PyTorch runtime: chunks + one contiguous mapping on both sides
+            VmmRegion* r = vmm_create(device_id, i, bytes);
+            if (!r) {
+                if (!error_is_fatal()) return;
+                fflush(stderr);
+                exit(EXIT_FAILURE);
+            }
+            e->vmm.push_back(r);
+            memcpy((void*)&e->shm->memHandle[device_id][i][1], &r->desc, sizeof(r->desc));
+            p = r->va;
+        } else {
+            p = ipc_alloc(e->shm, device_id, i, 1, bytes);
+        }
+        if (!p) return;   // refused or out of memory: the error is sticky, nothing is registered
         e->float_features[device_id].push_back(p);
     }
 }
@@ -267,7 +442,11 @@ void IPCEnv_Finalize(IPCEnv* e)
         DeviceGuard guard(i);
         for (size_t j = 0; j < e->ids[i].size(); j++) {
             (void)hipFree(e->ids[i][j]);
-            if (j < e->float_features[i].size()) (void)hipFree(e->float_features[i][j]);
+            if (j < e->float_features[i].size()) {
+                bool mapped = false;
+                for (VmmRegion* r : e->vmm) mapped = mapped || r->va == e->float_features[i][j];
+                if (!mapped) (void)hipFree(e->float_features[i][j]);
+            }
             (void)hipFree(e->labels[i][j]);
             (void)hipFree(e->agg_src[i][j]);
             (void)hipFree(e->agg_dst[i][j]);
@@ -280,6 +459,8 @@ void IPCEnv_Finalize(IPCEnv* e)
         }
         e->ids[i].clear();
     }
+    for (VmmRegion* r : e->vmm) { DeviceGuard guard(r->device); vmm_release(r); }
+    e->vmm.clear();
     if (e->shm) {
         munmap((void*)e->shm, sizeof(shmStruct));
         close(e->shm_fd);
@@ -304,7 +485,46 @@ struct LegionIPCClient {
     int32_t steps[3] = {0, 0, 0};
     int32_t hops = 2;
     int current_pipe = 0;
+    // feature buffers that arrived as chunk descriptors (see VmmDesc): what to unmap / release on close
+    struct Mapped { void* va = nullptr; size_t total = 0; std::vector<hipMemGenericAllocationHandle_t> handles; };
+    Mapped mapped[LEGION_PIPELINE_DEPTH];
 };
+
+// trainer side of a chunked hand-off buffer: fetch the descriptors, import, map back to back
+static void* vmm_attach(LegionIPCClient* c, int pipe, const VmmDesc& want)
+{
+    sockaddr_un addr;
+    const socklen_t len = vmm_sock_addr(&addr, c->device, pipe);
+    const int s = socket(AF_UNIX, SOCK_STREAM, 0);
+    bool ok = s >= 0;
+    for (int i = 0; ok && i < 100 && connect(s, (sockaddr*)&addr, len) != 0; i++) {
+        if (i == 99) ok = false;
+        usleep(100000);
+    }
+    VmmDesc d{};
+    ok = ok && recv(s, &d, sizeof(d), MSG_WAITALL) == (ssize_t)sizeof(d) && memcmp(&d, &want, sizeof(d)) == 0;
+    LegionIPCClient::Mapped& m = c->mapped[pipe];
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    ok = ok && hipMemAddressReserve(&m.va, d.total, 0, nullptr, 0) == hipSuccess;
+    if (ok) m.total = d.total;
+    for (uint32_t k = 0; ok && k < d.nchunks; k++) {
+        const int fd = recv_fd(s);
+        hipMemGenericAllocationHandle_t h;
+        ok = fd >= 0 && vmm_import_fd(&h, fd) == hipSuccess;
+        if (fd >= 0) close(fd);
+        if (!ok) break;
+        m.handles.push_back(h);
+        const size_t sz = std::min<size_t>(d.chunk, d.total - (size_t)k * d.chunk);
+        ok = hipMemMap((char*)m.va + (size_t)k * d.chunk, sz, 0, h, 0) == hipSuccess;
+    }
+    hipMemAccessDesc acc{};
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = cur; acc.flags = hipMemAccessFlagsProtReadWrite;
+    ok = ok && hipMemSetAccess(m.va, d.total, &acc, 1) == hipSuccess;
+    if (s >= 0) { if (ok) (void)!send(s, "d", 1, MSG_NOSIGNAL); close(s); }
+    if (!ok) { (void)hipGetLastError(); LEGION_ARG_ERROR("legion_ipc_client_open: attaching the chunked feature buffer failed"); return nullptr; }
+    return m.va;
+}
 
 extern "C" {
 
@@ -328,6 +548,12 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
         for (int w = 0; w < LEGION_MEMORY_USAGE; w++) {
             hipIpcMemHandle_t h;
             memcpy(&h, (const void*)&c->shm->memHandle[c->device][i][w], sizeof(h));
+            if (w == 1 && memcmp(&h, kVmmMagic, sizeof(kVmmMagic)) == 0) {   // a chunk descriptor, not an IPC handle
+                VmmDesc d;
+                memcpy(&d, &h, sizeof(d));
+                c->buf[i][w] = vmm_attach(c, i, d);
+                continue;
+            }
             HIP_CHECK(hipIpcOpenMemHandle(&c->buf[i][w], h, hipIpcMemLazyEnablePeerAccess));
         }
     }
@@ -371,8 +597,16 @@ void legion_ipc_client_close(LegionIPCClient* c)
 {
     if (!c) return;
     for (int i = 0; i < LEGION_PIPELINE_DEPTH; i++) {
-        for (int w = 0; w < LEGION_MEMORY_USAGE; w++)
-            if (c->buf[i][w]) (void)hipIpcCloseMemHandle(c->buf[i][w]);
+        for (int w = 0; w < LEGION_MEMORY_USAGE; w++) {
+            if (!c->buf[i][w]) continue;
+            if (w == 1 && c->mapped[i].va == c->buf[i][w]) {
+                (void)hipMemUnmap(c->mapped[i].va, c->mapped[i].total);
+                for (auto h : c->mapped[i].handles) (void)hipMemRelease(h);
+                (void)hipMemAddressFree(c->mapped[i].va, c->mapped[i].total);
+            } else {
+                (void)hipIpcCloseMemHandle(c->buf[i][w]);
+            }
+        }
         if (c->semw[i] && c->semw[i] != SEM_FAILED && sem_close(c->semw[i]) == -1) std::cout << "close sem " << i << " failed\n";
         if (c->semr[i] && c->semr[i] != SEM_FAILED) sem_close(c->semr[i]);
     }

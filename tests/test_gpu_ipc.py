@@ -223,7 +223,7 @@ def test_torch_link_prediction_trainer_on_triple_seeds(tmp_path, synth):
     assert len(losses) == epochs and losses[-1] < 1.2 < 2 * np.log(2) + 0.2, tr.stdout
 
 
-def _serve(tmp_path, spec, meta_line, fan, G, agg_mode, epochs, extra_env=None, client_env=None):
+def _serve(tmp_path, spec, meta_line, fan, G, agg_mode, epochs, extra_env=None, client_env=None, client="ipc_client.py"):
     """Start `legion G agg_mode fan meta`, one ipc_client per GPU; returns ([client json per GPU], server log text)."""
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
@@ -239,7 +239,7 @@ def _serve(tmp_path, spec, meta_line, fan, G, agg_mode, epochs, extra_env=None, 
         _wait_ready(server, log)
         for g in range(G):
             out = str(tmp_path / ("client%d.json" % g))
-            clients.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_client.py"), str(spec.F), str(epochs), out],
+            clients.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", client), str(spec.F), str(epochs), out],
                                                   env=dict(env, LEGION_IPC_DEVICE=str(g), **(client_env or {})), stdout=subprocess.PIPE,
                                                   stderr=subprocess.STDOUT, text=True)))
         for out, c in clients:
@@ -324,3 +324,56 @@ def test_two_gpu_server_link_prediction_lists_keep_their_thirds(tmp_path, synth,
                 row = ds.indices[ds.indptr[s_]:ds.indptr[s_ + 1]]
                 assert p_ == s_ or p_ in row
         assert n_train == steps[0]
+
+
+@pytest.mark.parametrize("client", ["ipc_client.py", "ipc_client_plain.py"])
+def test_chunked_feature_handoff_buffer(tmp_path, synth, oracle, client):
+    """A feature hand-off buffer above the HIP-IPC size limit (2^31 bytes under the PyTorch-bundled runtime) is built from
+    chunks, exported as file descriptors and mapped contiguously by the trainer (ipc_env.cpp, VmmDesc).  Forced here with a
+    tiny limit and 1 MiB chunks (a ~3 MB buffer = 3 chunks per pipe); the PyTorch client imports through the bundled ROCm 7.0
+    runtime (descriptor by pointer), the plain ctypes client through the system runtime (by value)."""
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    data = str(tmp_path / "ds") + "/"
+    synth.write_legion_files(ds, data)
+    B, epochs, fan = 512, 1, [10, 5]
+    got, text = _serve(tmp_path, spec, synth.meta_config_line(ds, data, B, 1 << 40, epochs, 0), fan, 1, 0, epochs,
+                       extra_env={"LEGION_IPC_MAX_BYTES": "1000000", "LEGION_HANDOFF_CHUNK_BYTES": "1048576"}, client=client)
+    steps, tb, vb, sb = oracle.coordinate([len(ds.train)], [len(ds.valid)], [len(ds.test)], B)
+    bs = {0: int(tb[0]), 1: int(vb[0]), 2: int(sb[0])}
+    sets = {0: ds.train, 1: ds.valid, 2: ds.test}
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+    assert len(got[0]["batches"]) == oracle.max_step(steps, epochs)
+    for rec in got[0]["batches"]:
+        mode, local = oracle.schedule(steps, epochs, rec["b"])
+        ref = orc.run_batch(sets[mode], ds.labels[sets[mode]], local, mode=mode, batch_size=bs[mode])
+        assert rec["n"] == ref["nc"][9] and rec["n"] * spec.F * 4 > 1048576        # the rows span several chunks
+        assert rec["ids"] == sha(ref["ids"]) and rec["features"] == sha(ref["features"]) and rec["labels"] == sha(ref["labels"])
+        assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
+
+
+def test_three_gigabyte_feature_buffer_reaches_a_pytorch_process(tmp_path):
+    """6.5 M rows x 128 floats = 3.1 GiB per pipe: above the 2^31-byte limit at which the PyTorch-bundled runtime's
+    hipIpcOpenMemHandle hangs (profiles/r02_ipc_limit.md).  The server side (no PyTorch: system runtime) builds it from
+    1 GiB chunks; the PyTorch process attaches through legion_ipc_client_open and finds the right rows at the start, the
+    end and on both sides of every chunk seam."""
+    rows, F = 6_500_000, 128
+    assert rows * F * 4 > 2 ** 31
+    ns = "big%d_" % os.getpid()
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = os.path.join(ROOT, "tests", "handoff_big.py")
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:      # a file, polled with a deadline: never block on the server's pipe
+        server = subprocess.Popen([sys.executable, script, "server", str(rows), str(F)], env=env, stdout=lf, stderr=subprocess.STDOUT)
+    try:
+        t0 = time.time()
+        while "ready" not in open(log, errors="ignore").read():
+            assert server.poll() is None and time.time() - t0 < 120, open(log, errors="ignore").read()[-2000:]
+            time.sleep(0.2)
+        client = subprocess.run([sys.executable, script, "client", str(rows), str(F)], env=env, capture_output=True, text=True, timeout=180)
+        assert client.returncode == 0 and "0 mismatches" in client.stdout, client.stdout[-2000:] + client.stderr[-2000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0 and "server: done" in open(log).read(), open(log).read()[-2000:]
+    finally:
+        if server.poll() is None:
+            server.kill()

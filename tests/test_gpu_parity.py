@@ -729,15 +729,21 @@ def test_ipc_exports_above_the_limit_are_refused(K, small_ds, monkeypatch):
     assert L.GPUCache_ExportFeatureShard(eng.cache, 0, h) == -1
     with pytest.raises(RuntimeError, match="HIP-IPC limit"):
         K.check()
-    # the trainer hand-off buffers: 1000 rows x F x 4 bytes per pipe > limit -> refused, nothing allocated
+    # the trainer hand-off buffers: a sample buffer above the limit is refused, nothing registered ...
     env = L.NewIPCEnv(1)
-    L.IPCEnv_InitializeFeaturesBuffer(env, 0, 1000, ds.spec.F, 0, 1)
+    L.IPCEnv_InitializeSamplesBuffer(env, 100, 50000, ds.spec.F, 0, 1)        # 50 000 ids x 4 bytes = 200 kB > limit
     with pytest.raises(RuntimeError, match="HIP-IPC limit"):
         K.check()
-    monkeypatch.delenv("LEGION_IPC_MAX_BYTES")
-    L.IPCEnv_InitializeFeaturesBuffer(env, 0, 1000, ds.spec.F, 0, 1)
+    # ... while a FEATURE buffer above it is built from chunks and mapped contiguously (end to end: test_gpu_ipc.py)
+    monkeypatch.setenv("LEGION_HANDOFF_CHUNK_BYTES", "131072")
+    L.IPCEnv_InitializeFeaturesBuffer(env, 0, 1000, ds.spec.F, 0, 1)          # 400 kB = 4 chunks
     K.check()
-    assert L.IPCEnv_GetFloatFeatures(env, 0, 0)
+    p = L.IPCEnv_GetFloatFeatures(env, 0, 0)
+    assert p
+    pattern = np.arange(1000 * ds.spec.F, dtype=np.float32)
+    L.d_copy_h_2_d(p, pattern.ctypes.data, pattern.nbytes)                    # one copy across the chunk seams
+    assert np.array_equal(K.read_dev(p, np.float32, pattern.size), pattern)
+    monkeypatch.delenv("LEGION_IPC_MAX_BYTES")
     L.IPCEnv_Finalize(env)
     eng.close()
 

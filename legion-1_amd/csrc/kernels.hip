@@ -264,6 +264,8 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                     // greater: unseen.  A stale (larger) pre-filter read only costs a redundant atomic.
                     const unsigned long long prov0 = ((unsigned long long)epoch << 32) | kProvisional;
                     const unsigned long long mine = prov0 | (uint32_t)idx;
+                    // (plain loads: a non-temporal hint on this pre-filter load costs +11 % of k_sample, on the neighbour load
+                    // nothing, profiles/r02_sampler_experiments.md)
                     unsigned long long cur = a.pos_map[dst];
                     if (cur > mine) {
                         const unsigned long long old = atomicMin(a.pos_map + dst, mine);

@@ -36,7 +36,7 @@ def meta_line(args) -> str:
     name, V, E, F, n_train, n_valid, n_test = DATASETS[args.dataset]
     path = args.dataset_path + "/" + name + "/"
     return "{} {} {} {} {} {} {} {} {} {} {}".format(path, args.train_batch_size, V, E, F, n_train, n_valid, n_test,
-                                                    args.cache_memory, args.epoch, 1 - args.usenvlink)
+                                                    args.cache_memory, args.epoch, 2 if args.seed_lists else 1 - args.usenvlink)
 
 
 def main(argv=None):
@@ -50,6 +50,8 @@ def main(argv=None):
     ap.add_argument("--epoch", type=int, default=10)
     ap.add_argument("--cache_memory", type=int, default=38000000000)
     ap.add_argument("--usenvlink", type=int, default=1, help="1: cliques over the GPU interconnect (xGMI)")
+    ap.add_argument("--seed_lists", action="store_true", help="extension (link prediction on several GPUs): every GPU g serves its own "
+                    "pre-partitioned list trainingset_<G>_<g> verbatim (meta_config flag 2) instead of a split of `trainingset`")
     ap.add_argument("--dry_run", action="store_true", help="write meta_config and print the command only")
     args = ap.parse_args(argv)
     fan = [int(x) for x in args.nbrs_num.replace("[", "").replace("]", "").split(",") if x.strip()]

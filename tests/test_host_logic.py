@@ -169,6 +169,11 @@ def test_launcher_meta_config_line():
 
     class A:
         dataset_path, dataset, train_batch_size, cache_memory, epoch, usenvlink = "/home/atc-artifacts-user/datasets", "UKS", 8000, 32000000000, 10, 1
+        seed_lists = False
     assert ls.meta_line(A) == "/home/atc-artifacts-user/datasets/ukunion/ 8000 133633040 5507679822 256 13363304 100000 100000 32000000000 10 0"
     assert ls.cache_agg_mode(8, 1) == 1 and ls.cache_agg_mode(1, 1) == 0 and ls.cache_agg_mode(8, 0) == 0
     assert len(ls.meta_line(A).split()) == 11
+    A.usenvlink = 0
+    assert ls.meta_line(A).split()[-1] == "1"          # partition file, as the reference writes it (legion_server.py:59)
+    A.seed_lists = True                                # extension: per-GPU training lists (link prediction on G > 1 GPUs)
+    assert ls.meta_line(A).split()[-1] == "2"

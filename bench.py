@@ -307,7 +307,7 @@ def guarded_unified_leg(c, line):
             part = getattr(c, "partial_unified", None)
             line["unified_cache"] = dict(part, exchange_variant={"error": msg}) if part else {"error": msg}
             print(json.dumps(line), flush=True)
-        os._exit(0 if c.rank == 0 else 3)
+        os._exit(0)      # every rank: the line rank 0 printed carries the error; a non-zero rank would fail the whole launch
     timer = threading.Timer(c.args.unified_timeout, fire)
     timer.daemon = True
     timer.start()

@@ -786,3 +786,19 @@ def test_full_batch_bound_on_a_small_graph(K, oracle, synth):
         eng.run_batch(0, 0, per_level=False)
         assert_batch_equal(ref, eng.result(0))
     eng.close()
+
+
+def test_four_hops_at_the_full_batch_bound(K, oracle, synth):
+    """B = 8000, fan-out {25,10,5,2}: hop 4 is sized for 20 M slots = 19 532 tiles, so k_write's LDS prefix holds one entry per
+    FOUR tiles in blocks of 16 groups (gshift = 2, the 16-bit in-block prefixes then span 64 tiles) -- the coarsest layout a
+    realistic configuration reaches.  14 M edges on a 49 k-node graph: nearly every edge loses its claim and is resolved through
+    the grouped prefix."""
+    ds = synth.generate(synth.spec_for("products", scale=0.02))
+    B, fan = 8000, [25, 10, 5, 2]
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+    eng = make_engine(K, ds, B, fan)
+    ref = orc.run_batch(ds.train, ds.labels[ds.train], 0)
+    assert ref["ec"][6] > 10_000_000
+    eng.run_batch(0, 0, per_level=False)
+    assert_batch_equal(ref, eng.result(0))
+    eng.close()

@@ -1,3 +1,4 @@
+# NOTE: LEGION_GATHER_ITERS / LEGION_GATHER_MSHIFT were temporary env knobs of the round-2 sweep (profiles/r02_gather_grid_sweep.md) and no longer exist in launch_gather.
 set -e
 mkdir -p gpurun_out/r02g
 for it in 1 2 3 4; do for ms in 2 4 5; do

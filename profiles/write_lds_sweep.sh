@@ -1,3 +1,4 @@
+# NOTE: LEGION_WRITE_ENTRIES was a temporary env knob of the round-2 sweep (profiles/r02_write_lds_sweep.md); the shipped constant is kWriteEntries = 6144.
 # k_write: LDS prefix granularity vs occupancy (temporary knob LEGION_WRITE_ENTRIES), kernel averages from rocprofv3
 for e in 12288 6144 3072 1536; do
   d=$GRAFT_REPO_ROOT/gpurun_out/r02p/e$e

@@ -645,6 +645,20 @@ def roofline_of(c, leg):
         with open(pmc) as f:
             traffic = json.load(f)["k_gather"]["traffic_bytes_per_launch"]
         traffic_src = "profiles/" + os.path.basename(pmc)
+    # the sampler group (k_seed + 3 kernels per hop): everything of the serial batch that is not the gather
+    sampler = None
+    if not leg["intra"] and not leg["overlap"]:
+        samp_us = leg["elapsed"] / args.steps * 1e6 - float(g_ms.mean()) * 1e3
+        samp_alg = float(leg["samp_bytes"].mean())
+        raw = None
+        if traffic_src:
+            with open(pmc) as f:
+                raw = json.load(f).get("sampler", {}).get("raw_over_algorithmic")
+        sampler = {"us_per_batch": round(samp_us, 1), "algorithmic_bytes_per_batch": int(samp_alg),
+                   "frac_of_peak_algorithmic": round(samp_alg / (samp_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                   "counter_bytes_over_algorithmic": raw,
+                   "frac_of_peak_counter_bytes": round(raw * samp_alg / (samp_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if raw else None,
+                   "bound": "random-access rate of the memory system (~50 G loads/s, ~26 G atomics/s), not bandwidth: profiles/r01_probe_rate.md"}
     return dict(bound="hbm", kernel="k_gather<float4, non-temporal>", achieved=round(ach, 1),
                 peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
                 traffic_measured_in_run=False if traffic is not None else None,
@@ -652,7 +666,7 @@ def roofline_of(c, leg):
                 avg_launch_us=round(float(g_ms.mean()) * 1e3, 2), timed_launches=int(len(g_ms)),
                 algorithmic_bytes_per_launch=int(launch_bytes.mean()),
                 launch="last level (hop %d rows) of the per-level gathers" % H if leg["intra"] else "all rows of the batch",
-                pipeline_frac=round(leg["job_bytes"] / leg["elapsed"] / 1e9 / (HBM_PEAK_GBPS * c.world), 4))
+                pipeline_frac=round(leg["job_bytes"] / leg["elapsed"] / 1e9 / (HBM_PEAK_GBPS * c.world), 4), sampler=sampler)
 
 
 def headline_line(c, leg):

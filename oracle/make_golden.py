@@ -145,10 +145,23 @@ def cache_fixture():
     return out
 
 
+def lp_seed_lists():
+    """Link-prediction seed lists ([src | pos | neg] thirds per batch, lp_sage.py:87-90) of synth.lp_trainingset: the 1-GPU list
+    and the two lists of a 2-GPU job (triples dealt by src % 2).  Pins the on-disk layout of `trainingset` / `trainingset_<G>_<g>`."""
+    spec = S.spec_for("products", scale=0.002)
+    ds = S.generate(spec, with_features=False)
+    n, B = 50, 30
+    out = {"workload": spec.name, "n_triples": n, "batch": B, "seed": 1, "lists": {}}
+    out["lists"]["1of1"] = S.lp_trainingset(ds, n, B).tolist()
+    for r in (0, 1):
+        out["lists"]["%dof2" % r] = S.lp_trainingset(ds, n, B, rank=r, world=2).tolist()
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     for name, fn in (("rng_kat", rng_kat), ("toy_batches", toy_cases), ("medium_digests", medium_digests),
-                     ("schedule_table", schedule_table), ("cache_fixture", cache_fixture)):
+                     ("schedule_table", schedule_table), ("cache_fixture", cache_fixture), ("lp_seed_lists", lp_seed_lists)):
         data = fn()
         with open(os.path.join(GOLD, name + ".json"), "w") as f:
             json.dump(data, f, separators=(",", ":"))

@@ -177,3 +177,23 @@ def test_launcher_meta_config_line():
     assert ls.meta_line(A).split()[-1] == "1"          # partition file, as the reference writes it (legion_server.py:59)
     A.seed_lists = True                                # extension: per-GPU training lists (link prediction on G > 1 GPUs)
     assert ls.meta_line(A).split()[-1] == "2"
+
+
+def test_lp_seed_lists_golden(synth):
+    """synth.lp_trainingset against tests/golden/lp_seed_lists.json (the layout `trainingset` / `trainingset_<G>_<g>` files have):
+    [src | pos | neg] thirds per batch, positives are neighbours of their source, the 2-GPU lists re-deal the 1-GPU triples by src % 2."""
+    from conftest import load_golden
+    import numpy as np
+    g = load_golden("lp_seed_lists")
+    ds = synth.generate(synth.spec_for("products", scale=0.002), with_features=False)
+    n, B = g["n_triples"], g["batch"]
+    k = B // 3
+    assert synth.lp_trainingset(ds, n, B).tolist() == g["lists"]["1of1"]
+    for r in (0, 1):
+        assert synth.lp_trainingset(ds, n, B, rank=r, world=2).tolist() == g["lists"]["%dof2" % r]
+    one = np.array(g["lists"]["1of1"]).reshape(-1, 3, k)
+    for b in range(one.shape[0]):
+        for s_, p_ in zip(one[b, 0], one[b, 1]):
+            assert p_ == s_ or p_ in ds.indices[ds.indptr[s_]:ds.indptr[s_ + 1]]
+    triples = lambda lst: {tuple(t) for t in np.array(lst).reshape(-1, 3, k).transpose(0, 2, 1).reshape(-1, 3).tolist()}   # noqa: E731
+    assert triples(g["lists"]["0of2"]) | triples(g["lists"]["1of2"]) == triples(g["lists"]["1of1"])

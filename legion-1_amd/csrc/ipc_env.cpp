@@ -131,12 +131,24 @@ static void vmm_serve(VmmRegion* r)
     while (!r->stop.load()) {
         pollfd p{r->listen_fd, POLLIN, 0};
         if (poll(&p, 1, 200) <= 0) continue;
-        const int s = accept(r->listen_fd, nullptr, nullptr);
+        const int s = accept4(r->listen_fd, nullptr, nullptr, SOCK_CLOEXEC);
         if (s < 0) continue;
-        bool ok = send(s, &r->desc, sizeof(r->desc), MSG_NOSIGNAL) == (ssize_t)sizeof(r->desc);
+        // the descriptors are read/write dmabuf handles of the feature buffer: only hand them to a process of this user,
+        // and never let a stalled client hold the serving thread (IPCEnv_Finalize joins it)
+        timeval tv{2, 0};
+        (void)setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+        (void)setsockopt(s, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
+        ucred cred{};
+        socklen_t cl = sizeof(cred);
+        bool ok = getsockopt(s, SOL_SOCKET, SO_PEERCRED, &cred, &cl) == 0 && cred.uid == geteuid();
+        ok = ok && send(s, &r->desc, sizeof(r->desc), MSG_NOSIGNAL) == (ssize_t)sizeof(r->desc);
         for (size_t i = 0; ok && i < r->fds.size(); i++) ok = send_fd(s, r->fds[i]);
-        char ack;
-        if (ok) (void)!recv(s, &ack, 1, 0);        // the trainer closes after it has mapped everything
+        // the trainer acknowledges after it has mapped everything; wait for it in slices so that a shutdown is never blocked
+        for (int waited = 0; ok && waited < 30 && !r->stop.load(); waited++) {
+            char ack;
+            const ssize_t n = recv(s, &ack, 1, 0);
+            if (n >= 0 || (errno != EAGAIN && errno != EWOULDBLOCK && errno != EINTR)) break;
+        }
         close(s);
     }
 }
@@ -193,7 +205,7 @@ static VmmRegion* vmm_create(int logical_dev, int pipe, size_t bytes)
     if (ok) {
         sockaddr_un addr;
         const socklen_t len = vmm_sock_addr(&addr, logical_dev, pipe);
-        r->listen_fd = socket(AF_UNIX, SOCK_STREAM, 0);
+        r->listen_fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
         ok = r->listen_fd >= 0 && bind(r->listen_fd, (sockaddr*)&addr, len) == 0 && listen(r->listen_fd, 8) == 0;
     }
     if (!ok) {
@@ -206,16 +218,22 @@ static VmmRegion* vmm_create(int logical_dev, int pipe, size_t bytes)
     r->server = std::thread(vmm_serve, r);
     return r;
 }
-// osHandle: the ROCm 7.0 runtime (torch wheel) dereferences it as int*, ROCm 7.2 takes the descriptor by value (like CUDA).
-// By pointer first: 7.2 then sees a huge, unopened descriptor number and fails cleanly; by value first would crash 7.0.
+// osHandle: the ROCm 7.0 runtime (the one bundled with the torch wheel, hipRuntimeGetVersion 70051831) dereferences it as
+// int*, ROCm 7.2 (70226015) takes the descriptor by value (like CUDA).  The convention is picked ONCE from the version of the
+// runtime this process really loaded -- no trial call: a genuine failure of the first form (stale fd, out of memory) must come
+// back as an error, not be retried in the form that makes the other runtime dereference a small integer.
 static hipError_t vmm_import_fd(hipMemGenericAllocationHandle_t* h, int fd)
 {
-    static int fd_cell;        // static storage: the low 32 bits of its address are never a small (open) descriptor number
+    static int by_pointer = -1;
+    if (by_pointer < 0) {
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
+        const char* e = getenv("LEGION_VMM_FD_BY_POINTER");          // override for a runtime that reports an unexpected version
+        by_pointer = e ? (atoi(e) != 0) : (v < 70100000);
+    }
+    static thread_local int fd_cell;
     fd_cell = fd;
-    hipError_t r = hipMemImportFromShareableHandle(h, (void*)&fd_cell, hipMemHandleTypePosixFileDescriptor);
-    if (r == hipSuccess) return r;
-    (void)hipGetLastError();
-    return hipMemImportFromShareableHandle(h, (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
+    return hipMemImportFromShareableHandle(h, by_pointer ? (void*)&fd_cell : (void*)(uintptr_t)fd, hipMemHandleTypePosixFileDescriptor);
 }
 
 struct IPCEnv {
@@ -495,12 +513,15 @@ static void* vmm_attach(LegionIPCClient* c, int pipe, const VmmDesc& want)
 {
     sockaddr_un addr;
     const socklen_t len = vmm_sock_addr(&addr, c->device, pipe);
-    const int s = socket(AF_UNIX, SOCK_STREAM, 0);
+    const int s = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
     bool ok = s >= 0;
-    for (int i = 0; ok && i < 100 && connect(s, (sockaddr*)&addr, len) != 0; i++) {
-        if (i == 99) ok = false;
+    const char* te = getenv("LEGION_VMM_ATTACH_TIMEOUT_MS");
+    const int tries = std::max(1, (te && atoi(te) > 0 ? atoi(te) : 10000) / 100);
+    for (int i = 0; ok && connect(s, (sockaddr*)&addr, len) != 0; i++) {
+        if (i >= tries - 1) { ok = false; break; }
         usleep(100000);
     }
+    if (ok) { timeval tv{10, 0}; (void)setsockopt(s, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv)); }
     VmmDesc d{};
     ok = ok && recv(s, &d, sizeof(d), MSG_WAITALL) == (ssize_t)sizeof(d) && memcmp(&d, &want, sizeof(d)) == 0;
     LegionIPCClient::Mapped& m = c->mapped[pipe];
@@ -522,7 +543,25 @@ static void* vmm_attach(LegionIPCClient* c, int pipe, const VmmDesc& want)
     acc.location.type = hipMemLocationTypeDevice; acc.location.id = cur; acc.flags = hipMemAccessFlagsProtReadWrite;
     ok = ok && hipMemSetAccess(m.va, d.total, &acc, 1) == hipSuccess;
     if (s >= 0) { if (ok) (void)!send(s, "d", 1, MSG_NOSIGNAL); close(s); }
-    if (!ok) { (void)hipGetLastError(); LEGION_ARG_ERROR("legion_ipc_client_open: attaching the chunked feature buffer failed"); return nullptr; }
+    if (!ok) {
+        (void)hipGetLastError();
+        // give back whatever was reserved / imported / mapped so far: the caller refuses the whole client
+        if (m.va) {
+            size_t off = 0;
+            for (size_t k = 0; k < m.handles.size(); k++) {
+                const size_t sz = std::min<size_t>(d.chunk, d.total - off);
+                (void)hipMemUnmap((char*)m.va + off, sz);        // fails harmlessly for the one chunk that was imported but not mapped
+                off += sz;
+            }
+            for (auto h : m.handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(m.va, m.total);
+            (void)hipGetLastError();
+        }
+        m = LegionIPCClient::Mapped();
+        legion_clear_error();   // this is why the client is refused: let it be the error the caller reads
+        LEGION_ARG_ERROR("legion_ipc_client_open: attaching the chunked feature buffer failed");
+        return nullptr;
+    }
     return m.va;
 }
 
@@ -552,6 +591,10 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
                 VmmDesc d;
                 memcpy(&d, &h, sizeof(d));
                 c->buf[i][w] = vmm_attach(c, i, d);
+                if (!c->buf[i][w]) {   // no trainer may run on a null feature buffer: close what was opened, post nothing
+                    legion_ipc_client_close(c);
+                    return nullptr;
+                }
                 continue;
             }
             HIP_CHECK(hipIpcOpenMemHandle(&c->buf[i][w], h, hipIpcMemLazyEnablePeerAccess));

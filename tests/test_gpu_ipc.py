@@ -377,3 +377,16 @@ def test_three_gigabyte_feature_buffer_reaches_a_pytorch_process(tmp_path):
     finally:
         if server.poll() is None:
             server.kill()
+
+
+def test_client_open_refuses_a_chunk_descriptor_without_listener_gpu():
+    """Same refusal as the CPU test, with a real device behind it: no mapping may survive (the reserve / import / map steps
+    that ran are undone) and the process can still allocate afterwards.  Runs in a child: the trainer half is per process."""
+    code = ("import sys, os; sys.path[:0] = [%r, %r]\n"
+            "from test_host_logic import _client_open_without_listener\n"
+            "import legion1_amd.capi as K\n"
+            "K.lib().SetGPUDevice(0)\n"
+            "_client_open_without_listener('lgn_t_nolisten_gpu_%%d_' %% os.getpid())\n"
+            "b = K.DevBuf(1 << 20); b.free(); print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

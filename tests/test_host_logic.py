@@ -197,3 +197,40 @@ def test_lp_seed_lists_golden(synth):
             assert p_ == s_ or p_ in ds.indices[ds.indptr[s_]:ds.indptr[s_ + 1]]
     triples = lambda lst: {tuple(t) for t in np.array(lst).reshape(-1, 3, k).transpose(0, 2, 1).reshape(-1, 3).tolist()}   # noqa: E731
     assert triples(g["lists"]["0of2"]) | triples(g["lists"]["1of2"]) == triples(g["lists"]["1of1"])
+
+
+def _client_open_without_listener(tmp_ns):
+    """a feature-buffer slot that holds a chunk descriptor (LGNVMM01) whose server socket is not there must
+    make legion_ipc_client_open fail as a whole -- null client, sticky error, no semaphore posted, nothing left mapped --
+    instead of handing the trainer a null feature tensor."""
+    import struct
+    import legion1_amd.capi as K
+    L = K.lib()
+    L.legion_set_error_mode(K.ERR_RETURN)
+    L.legion_clear_error()
+    L.legion_ipc_set_namespace(tmp_ns.encode())
+    size = 12 + 8 * 2 * 7 * 64 + 4
+    path = "/dev/shm/" + tmp_ns + "simpleIPCshm"
+    desc = b"LGNVMM01" + struct.pack("<QQII", 1 << 21, 1 << 21, 1, 0)
+    slab = bytearray(size)
+    for pipe in range(2):
+        off = 12 + ((0 * 2 + pipe) * 7 + 1) * 64
+        slab[off:off + len(desc)] = desc
+    with open(path, "wb") as f:
+        f.write(slab)
+    os.environ["LEGION_VMM_ATTACH_TIMEOUT_MS"] = "300"
+    try:
+        client = L.legion_ipc_client_open(0)
+        msg = L.legion_last_error()
+        assert not client, "client must be refused"
+        assert msg and b"attaching the chunked feature buffer failed" in msg, msg
+        assert not os.path.exists("/dev/shm/sem." + tmp_ns + "sem_r_0_0"), "no pipe may be posted as free"
+    finally:
+        os.environ.pop("LEGION_VMM_ATTACH_TIMEOUT_MS", None)
+        L.legion_clear_error()
+        L.legion_ipc_set_namespace(b"")
+        os.unlink(path)
+
+
+def test_client_open_refuses_a_chunk_descriptor_without_listener():
+    _client_open_without_listener("lgn_t_nolisten_%d_" % os.getpid())

@@ -288,8 +288,11 @@ int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk,
  * Every $LEGION_CACHE_HIT_PERIOD-th batch (default 500) the FindFeat pass of the cached gathers counts its hits into pinned,
  * device-mapped words; "<dev> Feature Cache Hit: <ratio>" is printed when the next sampling starts (no blocking copy).
  * GPUCache_HitSampling is what the gather launchers call; GPUCache_FeatureCacheHitRate returns the newest completed
- * sample (hits / rows, -1 if none; synchronises the device). */
+ * sample (hits / rows, -1 if none; synchronises the device).
+ * The pinned words are read and cleared by the host without synchronising: GPUCache_HitSamplingDone records an event behind the
+ * last counting launch of a sampled batch, and a slot is only printed / reused once its event has completed. */
 int32_t* GPUCache_HitSampling(GPUCache* c, int32_t dev_id, int last_launch_of_batch, int first_launch_of_batch);
+void GPUCache_HitSamplingDone(GPUCache* c, int32_t dev_id, void* stream);
 double GPUCache_FeatureCacheHitRate(GPUCache* c, int32_t dev_id, int32_t* hits_out, int32_t* rows_out);
 uint64_t* GPUCache_GetNodeAccessedMap(const GPUCache* c, int32_t dev_id);
 uint64_t* GPUCache_GetEdgeAccessedMap(const GPUCache* c, int32_t dev_id);
@@ -408,6 +411,9 @@ Runner* NewGPURunner(void);
 void Runner_Initialize(Runner* r, RunnerParams* params);
 void Runner_InitializeFeaturesBuffer(Runner* r, RunnerParams* params);
 void Runner_RunPreSc(Runner* r, RunnerParams* params);
+/* RunOnce, Server.cu:301-328.  A batch an operator refused (sticky error): LEGION_ERR_EXIT exits like the reference;
+ * LEGION_ERR_RETURN posts the pipe with every node-counter word = -1 (nc[0] == -1: "server failed", no valid batch has it)
+ * so that no consumer blocks forever on sem_w, and returns with the error still set. */
 void Runner_RunOnce(Runner* r, RunnerParams* params);
 void Runner_Finalize(Runner* r, RunnerParams* params);
 GPUMemoryPool* Runner_GetMemoryPool(Runner* r);

@@ -85,6 +85,7 @@ void GPUCache_InitializeCacheController(GPUCache* c, int32_t dev_id, int32_t tot
         memset(k->hit_stats, 0, 4 * sizeof(int32_t));
         HIP_CHECK(hipHostGetDevicePointer((void**)&k->hit_stats_dev, k->hit_stats, 0));
     }
+    for (int q = 0; q < 2; q++) { HIP_CHECK(hipEventCreateWithFlags(&k->hit_ev[q], hipEventDisableTiming)); k->hit_ev_armed[q] = false; }
     k->find_iter = 0; k->hit_samples = 0; k->last_hit_rate = -1.0;
     k->iter = 0;
     k->max_ids = 0;
@@ -138,6 +139,7 @@ void GPUCache_Finalize(GPUCache* c, int32_t dev_id)
     if (k->d_max_ids) (void)hipFree(k->d_max_ids);
     if (k->d_global_count) (void)hipFree(k->d_global_count);
     if (k->hit_stats) { (void)hipHostFree(k->hit_stats); k->hit_stats = nullptr; k->hit_stats_dev = nullptr; }
+    for (int q = 0; q < 2; q++) if (k->hit_ev[q]) { (void)hipEventDestroy(k->hit_ev[q]); k->hit_ev[q] = nullptr; k->hit_ev_armed[q] = false; }
     k->node_access_time = k->edge_access_time = nullptr;
     k->d_max_ids = k->d_global_count = nullptr;
     free_shard(c, dev_id);
@@ -160,21 +162,39 @@ int32_t* GPUCache_HitSampling(GPUCache* c, int32_t dev_id, int last_launch_of_ba
     int32_t* out = nullptr;
     if (sampled) {
         const int slot = k->hit_samples & 1;
+        // The host reads / clears the pinned words without synchronising, so a slot is only touched once the event recorded
+        // behind the launches that counted into it has completed (GPUCache_HitSamplingDone): with pipelined batches and a
+        // short period the previous sampling may still be in flight -- then its ratio is printed one sampling later, and
+        // a slot that is still being written is not handed out again (this batch is simply not sampled).
+        auto settled = [&](int q) { return !k->hit_ev_armed[q] || hipEventQuery(k->hit_ev[q]) == hipSuccess; };
         if (first_launch_of_batch) {
             int32_t* prev = k->hit_stats + 2 * (slot ^ 1);
-            if (k->hit_samples > 0 && prev[1] > 0) {
+            if (k->hit_samples > 0 && prev[1] > 0 && settled(slot ^ 1)) {
                 k->last_hit_rate = (double)prev[0] / (double)prev[1];
                 std::cout << dev_id << " Feature Cache Hit: " << k->last_hit_rate << std::endl;
+                prev[1] = 0;   // printed once
             }
-            k->hit_stats[2 * slot] = 0; k->hit_stats[2 * slot + 1] = 0;   // last written two samplings ago
+            if (settled(slot)) { k->hit_stats[2 * slot] = 0; k->hit_stats[2 * slot + 1] = 0; k->hit_ev_armed[slot] = false; }
         }
-        out = k->hit_stats_dev + 2 * slot;
+        (void)hipGetLastError();   // hipEventQuery's hipErrorNotReady is not an error
+        if (!k->hit_ev_armed[slot]) out = k->hit_stats_dev + 2 * slot;
     }
     if (last_launch_of_batch) {
-        if (sampled) k->hit_samples++;
+        if (sampled && out) k->hit_samples++;
         k->find_iter++;
     }
     return out;
+}
+// called by the launcher behind the last counting launch of a sampled batch (stream = the stream it ran on)
+void GPUCache_HitSamplingDone(GPUCache* c, int32_t dev_id, void* stream)
+{
+    if (!c || dev_id < 0 || dev_id >= c->device_count) return;
+    CacheController* k = c->ctl[dev_id];
+    if (!k->hit_stats_dev || k->hit_samples == 0) return;
+    const int slot = (k->hit_samples - 1) & 1;   // the sampling that just finished its launches
+    if (!k->hit_ev[slot]) return;
+    HIP_CHECK(hipEventRecord(k->hit_ev[slot], (hipStream_t)stream));
+    k->hit_ev_armed[slot] = true;
 }
 // the newest completed sample (synchronises the device): hits / rows of the last sampled batch, or -1 if there is none
 double GPUCache_FeatureCacheHitRate(GPUCache* c, int32_t dev_id, int32_t* hits_out, int32_t* rows_out)

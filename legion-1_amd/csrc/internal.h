@@ -43,6 +43,12 @@ constexpr uint32_t kProvisional = 0x80000000u; // | slot idx : claimed in the ru
 #endif
 constexpr int kTile = LEGION_KTILE;            // sampler slots per workgroup tile
 constexpr int kBlock = 256;                    // threads per workgroup
+static_assert(kTile >= kBlock && kTile <= 4096 && (kTile & (kTile - 1)) == 0, "LEGION_KTILE: a power of two in [256, 4096]");
+constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+// k_write packs the (edges, nodes) counted in front of a tile group INSIDE its prefix block into 16 bits each: a block of
+// 2^lpb groups of 2^gshift tiles may hold at most 65536 / kTile tiles, i.e. lpb + gshift <= kPrefixBits (6 at kTile = 1024)
+constexpr int kPrefixBits = 16 - ilog2_c(kTile);
+static_assert((1 << kPrefixBits) * kTile <= 65536 && kPrefixBits >= 4, "16-bit in-block tile prefix would overflow for this LEGION_KTILE");
 constexpr int kMaxParts = LEGION_MAX_DEVICE;
 
 // minstd_rand arithmetic (thrust::minstd_rand: x <- 48271 x mod 2^31-1), shared by the sampler and the generators
@@ -294,6 +300,8 @@ struct CacheController {              // PreSCCacheController, GPUCache.cu:239-5
     int32_t find_iter = 0;
     int32_t* hit_stats = nullptr;      // host view, 2 x {hits, rows}
     int32_t* hit_stats_dev = nullptr;  // device view
+    hipEvent_t hit_ev[2] = {nullptr, nullptr}; // recorded behind the last counting launch of the sampling that used slot k
+    bool hit_ev_armed[2] = {false, false};
     int32_t hit_samples = 0;           // samplings started
     double last_hit_rate = -1.0;       // what the last print showed
 };

@@ -417,7 +417,7 @@ struct WriteArgs {
     int32_t last_hop;       // positions of the nodes found in the last hop are never looked up through the table
     int32_t gshift;         // the LDS prefix holds one entry per 2^gshift tiles (sized from the static slot bound)
     int32_t lds_entries;    // entries of the dynamic LDS prefix array
-    int32_t lpb;            // log2 of the groups per prefix block: min(5, 6 - gshift)
+    int32_t lpb;            // log2 of the groups per prefix block: min(5, kPrefixBits - gshift)
     int32_t* aux_next;      // slot states of the next hop (the other buffer), set to "claim pending" here
     int32_t next_count;     // fan-out of the next hop (0: none)
     int32_t aux_cap;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
     // inter-workgroup hand-off (device-scope fences cost an L2 write-back + invalidate per XCD: profiles/r01_gather_sweep.md).
     // Layout: one entry per group of 2^gshift tiles (gshift == 0 unless the hop's static bound exceeds kWriteEntries
     // tiles: occupancy beats granularity, see kWriteEntries), groups in blocks of kPB = 2^lpb: s_tile[g] = (edges | nodes << 16) in front of group g INSIDE its block
-    // (both < 2^16: kPB * 2^gshift <= 64 tiles of <= 1024), s_blk[b] = (edges, nodes) in front of block b.
+    // (both < 2^16: kPB * 2^gshift <= 2^kPrefixBits tiles of kTile slots, static_assert in internal.h), s_blk[b] = (edges, nodes) in front of block b.
     extern __shared__ uint32_t s_tile[];
     int2* const s_blk = reinterpret_cast<int2*>(s_tile + a.lds_entries);
     const int32_t lpb = a.lpb, kPB = 1 << lpb;
@@ -1049,10 +1049,13 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     // LDS prefix: one packed entry per 2^gshift tiles (+ one pair per 32 entries), at most kWriteEntries entries
     w.gshift = 0;
     while (((max_tiles + (1 << w.gshift) - 1) >> w.gshift) > kWriteEntries) w.gshift++;
-    if (w.gshift > 6) { LEGION_ARG_ERROR("GPU_Random_Sampling: hop too large for the tile-prefix encoding"); return; }
-    w.lpb = std::min(5, 6 - w.gshift);
+    // lpb >= 1 keeps the block array at <= 4 bytes per entry: <= 48 KB of dynamic LDS at kWriteEntries (64 KB is the limit
+    // of a workgroup without opting in); that covers kWriteEntries * 2^(kPrefixBits - 1) tiles = 201 M slots per hop at kTile = 1024
+    if (w.gshift > kPrefixBits - 1) { LEGION_ARG_ERROR("GPU_Random_Sampling: hop too large for the tile-prefix encoding"); return; }
+    w.lpb = std::min(5, kPrefixBits - w.gshift);
     w.lds_entries = (((max_tiles + (1 << w.gshift) - 1) >> w.gshift) + 63) & ~63;
     const size_t lds = (size_t)w.lds_entries * sizeof(uint32_t) + (size_t)(w.lds_entries >> w.lpb) * sizeof(int2);
+    if (lds > 60 * 1024) { LEGION_ARG_ERROR("GPU_Random_Sampling: tile prefix exceeds the workgroup's LDS"); return; }
     // every workgroup builds the prefix once: launch no more of them than are resident together
     const int per_cu = std::max(1, std::min(8, (int)((140 * 1024) / (lds + 1024))));
     const int wgrid = grid_for(max_tiles, 1, per_cu);

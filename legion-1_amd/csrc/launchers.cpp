@@ -193,7 +193,10 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
                           int off_idx, int size_idx, int32_t rows_bound)
 {
     GatherArgs g;
-    if (gather_args(g, cache, noder, p, dev_id, off_idx, size_idx)) launch_gather((hipStream_t)strm_hdl, g, rows_bound);
+    if (!gather_args(g, cache, noder, p, dev_id, off_idx, size_idx)) return;
+    launch_gather((hipStream_t)strm_hdl, g, rows_bound);
+    // last counting launch of a sampled batch: the host may read the pinned {hits, rows} words once this event completes
+    if (g.hit_stats && (off_idx < 0 || off_idx == 3 + 2 * p->hops)) GPUCache_HitSamplingDone(cache, dev_id, strm_hdl);
 }
 
 // get_feature_kernel, Kernels.cu:706-748.  op_id 2l+1 gathers level l.

@@ -175,6 +175,24 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     } else {
         IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
     }
+    // LEGION_ERR_RETURN (embedding / tests) and a failed batch: never leave a trainer blocked on sem_w.  The batch in flight
+    // is handed over as usual; the failed pipe is posted with nc[0] = -1 (every counter word 0xFFFFFFFF), which no valid
+    // batch produces -- a consumer must treat it as "server failed" (the reference's behaviour, exit(EXIT_FAILURE), is what
+    // the default LEGION_ERR_EXIT mode does instead).
+    auto post_poisoned = [&]() {
+        if (r->pending) {
+            (void)hipEventSynchronize(r->done_ev[r->pending_pipe]);
+            IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+            r->pending = false;
+        }
+        (void)hipDeviceSynchronize();
+        int32_t* nc = IPCEnv_GetNodeCounter(env, r->local_dev_id, r->current_pipe);
+        if (nc) (void)hipMemset(nc, 0xFF, 16 * sizeof(int32_t));
+        (void)hipGetLastError();
+        IPCEnv_IPCPost(env, r->local_dev_id, r->current_pipe);
+        r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
+        GPUMemoryPool_SetCurrentPipe(r->memorypool, r->current_pipe);
+    };
     auto run_ops = [&]() {
         for (int i = 0; i < r->op_num; i++) {
             if (i % 2 == 1) HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[i - 1], 0));
@@ -200,6 +218,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
             if (!g) {
                 LEGION_ARG_ERROR("Runner_RunOnce: recording the batch graph failed");
                 if (error_is_fatal()) exit(EXIT_FAILURE);   // never leave the trainer waiting for a batch that will not come
+                post_poisoned();
                 return;
             }
         }
@@ -217,6 +236,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         // them to a trainer -- the reference's error behaviour is exit(EXIT_FAILURE) (Kernels.cuh:14-22).
         std::cout << "Runner_RunOnce: batch " << batch_id << " on GPU " << r->local_dev_id << " failed; server stops\n" << std::flush;
         if (error_is_fatal()) exit(EXIT_FAILURE);
+        post_poisoned();
         return;
     }
     if (r->pipelined) {

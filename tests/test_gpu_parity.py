@@ -2,6 +2,7 @@
 against the CPU oracle on the same seeded inputs -- bit exact for every id / index / counter and
 for the (verbatim copied) f32 feature rows.  Run on the GPU box with `pytest -m gpu`."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -242,6 +243,50 @@ def test_operator_plugin_api(K, oracle, small_ds):
         L.Operator_Delete(op)
     L.IPCEnv_Finalize(env)
     eng.close()
+
+
+def test_runner_posts_a_poisoned_pipe_when_an_operator_refuses(K, small_ds):
+    """LEGION_ERR_RETURN (the tests' mode): a batch an operator refused must not leave a consumer blocked on sem_w --
+    Runner_RunOnce posts the pipe with every node-counter word = -1 and keeps the error.  Here the
+    feature buffers were never registered (Runner_InitializeFeaturesBuffer skipped), so every FeatureExtractor refuses."""
+    import ctypes.util
+    ds = small_ds
+    B, fan = 300, [10, 5]
+    L = K.lib()
+    ns = "lgn_t_poison_%d_" % os.getpid()
+    L.legion_ipc_set_namespace(ns.encode())
+    eng = make_engine(K, ds, B, fan)
+    env = L.NewIPCEnv(1)
+    L.IPCEnv_Coordinate(env, C.byref(eng.info))
+    fan_arr = np.asarray(fan, dtype=np.int32)
+    rp = K.RunnerParams()
+    rp.device_id, rp.fanout, rp.hops = 0, fan_arr.ctypes.data, len(fan)
+    rp.cache, rp.graph, rp.noder, rp.env, rp.global_batch_id, rp.in_memory = eng.cache, eng.graph, eng.noder, env, 0, 1
+    runner = L.NewGPURunner()
+    L.Runner_Initialize(runner, C.byref(rp))
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    K.check()
+    libc = C.CDLL(ctypes.util.find_library("c") or "libc.so.6", use_errno=True)
+    libc.sem_open.restype = C.c_void_p
+    libc.sem_open.argtypes = [C.c_char_p, C.c_int]
+    libc.sem_post.argtypes = libc.sem_trywait.argtypes = libc.sem_close.argtypes = [C.c_void_p]
+    sem_r = libc.sem_open(("/%ssem_r_0_0" % ns).encode(), 0)
+    sem_w = libc.sem_open(("/%ssem_w_0_0" % ns).encode(), 0)
+    assert sem_r and sem_w
+    libc.sem_post(sem_r)                       # the trainer's "pipe 0 is free"
+    L.Runner_RunOnce(runner, C.byref(rp))      # must return, not block and not exit
+    msg = L.legion_last_error()
+    assert msg and b"feature buffer of the current pipe is not set" in msg, msg
+    assert libc.sem_trywait(sem_w) == 0, "the failed pipe was not posted: a consumer would block forever"
+    nc = K.read_dev(L.IPCEnv_GetNodeCounter(env, 0, 0), np.int32, 16)
+    assert (nc == -1).all(), nc
+    L.legion_clear_error()
+    libc.sem_close(sem_r)
+    libc.sem_close(sem_w)
+    L.Runner_Delete(runner)
+    L.IPCEnv_Finalize(env)
+    eng.close()
+    L.legion_ipc_set_namespace(b"")
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+LEG_HUNG_EXIT = 3     # exit code of every rank when a leg after the headline hung: the line was printed, "legs_failed" names the leg
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E vendor peak (/opt/skills/guides/MI355X_MICROARCH.md)
 XGMI_PEAK_GBPS = 7 * 153.0  # 7 point-to-point links x ~153 GB/s per GPU
 
@@ -54,8 +55,15 @@ def parse(argv=None):
                          "hotness-partitioned feature cache of the reference (rank-t row on GPU t %% N), peer shards read in-kernel over xGMI")
     ap.add_argument("--no-unified-leg", action="store_true", help="N > 1: skip the unified-cache leg that follows the replicated headline")
     ap.add_argument("--no-exchange-leg", action="store_true", help="N > 1: skip the owner-computes exchange variant of the unified-cache gather")
-    ap.add_argument("--unified-timeout", type=float, default=420.0,
+    ap.add_argument("--unified-timeout", type=float, default=240.0,
                     help="N > 1: seconds the unified-cache leg may take before the headline line is printed without it")
+    ap.add_argument("--extra-legs", default="auto",
+                    help="comma list of further legs run by the same processes after the headline (+ unified) leg and reported in the same "
+                         "line: lp (BASELINE config 5: link-prediction seed batches on the papers100M graph, B = 7998), uk_union (config 4: "
+                         "uk-union shape, 2-hop {25,10}, CSR sharded over the clique + capped feature cache).  auto = both when N > 1 and the "
+                         "workload is the default one, none at N = 1; 'none' disables")
+    ap.add_argument("--extra-timeout", type=float, default=150.0, help="seconds each extra leg may take")
+    ap.add_argument("--extra-min-time", type=float, default=1.0, help="--min-time of the extra legs")
     ap.add_argument("--table", default="device", choices=["device", "host"],
                     help="where the V x F feature table lives: HBM (default) or pinned host memory read over PCIe -- the "
                          "reference's UVA configuration (GPUGraphStore.cu:315); combine with --cache unified for an HBM cache")
@@ -63,9 +71,9 @@ def parse(argv=None):
     ap.add_argument("--topo-frac", type=float, default=0.0, help="unified: fraction of the V adjacency rows cached as partitioned CSR "
                     "fragments per clique (0: topology stays replicated)")
     ap.add_argument("--presc-steps", type=int, default=8, help="unified: batches of the pre-sampling (hotness) epoch")
-    ap.add_argument("--min-time", type=float, default=0.5,
+    ap.add_argument("--min-time", type=float, default=3.0,
                     help="the K-step timed window is repeated until this many seconds are covered; ms_per_step is the median window")
-    ap.add_argument("--max-reps", type=int, default=60)
+    ap.add_argument("--max-reps", type=int, default=400)
     ap.add_argument("--skew", type=int, default=205, help="synthetic neighbours: n/256 of them drawn from the Zipf-like skew "
                     "(205 = the spec'd 80 %%; 0 = uniform neighbours, the Infinity-Cache control run)")
     ap.add_argument("--headline-only", action="store_true", help="skip the alt_schedule and graph_replay legs (clean kernel profiles)")
@@ -75,7 +83,11 @@ def parse(argv=None):
                     "the sampler stream and the rest the gather stream (hipExtStreamCreateWithCUMask); 0 = unrestricted streams")
     ap.add_argument("--cu-pattern", default="mod", choices=["mod", "block"], help="--cu-split: bit i belongs to the sampler if "
                     "i %% 8 < S (mod) or (i // 32) %% 8 < S (block)")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--row-pitch", default="auto", choices=["auto", "dense"],
+                    help="row pitch of the HBM feature table: auto = legion_row_pitch(F) (rows start on a 128-byte line: F = 100 -> 128 "
+                         "floats; F = 128 / 256 are dense anyway), dense = F (the reference's file layout)")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
+                    help="CPU time budget of the baseline legs together (60 %% reference-semantics oracle, 40 %% DGL-semantics sampler); 0 disables")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the parent gives up on its ranks")
     return ap.parse_args(argv)
@@ -141,6 +153,10 @@ def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0
     codes = [p.returncode for p in procs]
     if any(codes):
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        if all(c in (0, LEG_HUNG_EXIT) or (c is not None and c < 0) for c in codes) and LEG_HUNG_EXIT in codes:
+            print("bench.py: the headline line was printed, but a later leg did not finish in time (see \"legs_failed\" in the line)",
+                  file=sys.stderr)
+            return LEG_HUNG_EXIT
         return next((c for c in codes if c and c > 0), 1)      # a rank's own exit code; 1 if only stragglers were stopped
     return 0
 
@@ -148,8 +164,9 @@ def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0
 # ======================================================================================================
 # worker: one rank
 # ======================================================================================================
-def build_graph_on_gpu(K, spec, dev, skew=205):
-    """Synthetic dataset generated on the GPU by csrc/synth.hip (spec: legion-1_amd/synth.py)."""
+def build_graph_on_gpu(K, spec, dev, skew=205, pitch=0):
+    """Synthetic dataset generated on the GPU by csrc/synth.hip (spec: legion-1_amd/synth.py).  pitch > F: the feature
+    rows are laid out with that many floats between two rows (same values)."""
     import torch
     L = K.lib()
     V, F = spec.V, spec.F
@@ -162,8 +179,12 @@ def build_graph_on_gpu(K, spec, dev, skew=205):
     E = int(indptr[-1].item())
     indices = torch.empty(E, dtype=torch.int32, device=dev)
     L.legion_synth_neighbors_skew(None, indices.data_ptr(), 0, E, V, spec.M, spec.C, skew)
-    feats = torch.empty((V, F), dtype=torch.float32, device=dev)
-    L.legion_synth_features(None, feats.data_ptr(), 0, V, F)
+    if pitch > F:
+        feats = torch.zeros((V, pitch), dtype=torch.float32, device=dev)
+        L.legion_synth_features_pitched(None, feats.data_ptr(), 0, V, F, pitch)
+    else:
+        feats = torch.empty((V, F), dtype=torch.float32, device=dev)
+        L.legion_synth_features(None, feats.data_ptr(), 0, V, F)
     torch.cuda.synchronize()
     K.check()
     return indptr, indices, feats, E
@@ -209,16 +230,62 @@ def worker(args):
     import legion1_amd.synth as S
     c.K, c.D, c.S = K, D, S
     c.L = L = K.lib()
-    c.fan = fan = [int(x) for x in args.fanout.split(",")]
-    c.H = len(fan)
-    c.B = B = args.batch
-    c.spec = spec = S.spec_for(args.workload, scale=args.scale)
-    V, F = spec.V, spec.F
+    c.fan = [int(x) for x in args.fanout.split(",")]
+    c.H = len(c.fan)
+    c.B = args.batch
+    if args.row_pitch == "dense":
+        os.environ["LEGION_ROW_PITCH"] = "dense"      # cache shards too
     L.legion_set_device_map(0, local_rank)
     L.SetGPUDevice(0)
+    load_workload(c, args.workload)
+
+    head = run_leg(c, unified=(args.cache == "unified"), headline=True)
+    line = headline_line(c, head) if rank == 0 else {"legs_failed": [], "extra_legs": {}}
+    c.guard = guard = LegGuard(c, line)
+
+    if world > 1 and args.cache == "replicated" and not args.no_unified_leg and args.table == "device":
+        line["unified_cache"] = guard.run("unified_cache", args.unified_timeout,
+                                          lambda: unified_summary(c, run_leg(c, unified=True, headline=False, min_time=args.extra_min_time)))
+
+    # measured streaming-copy rate of this box (float4 copy kernel sized like the gather, read + write bytes)
+    if rank == 0 and line.get("roofline") is not None:
+        line["roofline"]["measured_copy_GBps"] = measure_copy(c)
+    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
+        feats = c.feats
+        if c.host_table is not None:   # the table already is host memory: view it, no copy
+            import ctypes
+            feats = np.ctypeslib.as_array(ctypes.cast(c.host_table, ctypes.POINTER(ctypes.c_float)), shape=(c.spec.V, c.spec.F))
+        try:
+            line["cpu_baseline"] = run_cpu_baseline(args, c.spec, c.indptr, c.indices, feats, c.mine, c.my_labels, c.B, c.fan, c.steps_avail)
+        except Exception as ex:   # noqa: BLE001 -- reported baseline only: never lose the headline line over it
+            line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
+
+    for name in extra_leg_names(c):      # BASELINE configs 4 and 5, same processes, same line (after everything that needs the headline graph)
+        line["extra_legs"][name] = guard.run(name, args.extra_timeout, lambda name=name: extra_leg(c, name))
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def load_workload(c, workload):
+    """(Re)build the synthetic graph of `workload` on this rank's GPU and this rank's seed list; frees the previous one first."""
+    import torch
+    args, K, L, S = c.args, c.K, c.L, c.S
+    for name in ("indptr", "indices", "feats", "mine", "my_labels"):
+        setattr(c, name, None)
+    if getattr(c, "host_table", None) is not None:
+        L.host_free_space(c.host_table)
+    c.host_table = None
+    torch.cuda.empty_cache()
+    c.spec = spec = S.spec_for(workload, scale=args.scale)
+    V, F = spec.V, spec.F
     t0 = time.time()
-    c.indptr, c.indices, c.feats, c.E = build_graph_on_gpu(K, spec, dev, args.skew)
-    c.feat_ptr, c.feat_loc, c.host_table = c.feats.data_ptr(), K.LOC_DEVICE, None
+    c.pitch = L.legion_row_pitch(F) if args.table == "device" else F
+    c.indptr, c.indices, c.feats, c.E = build_graph_on_gpu(K, spec, c.dev, args.skew, c.pitch)
+    c.feat_ptr, c.feat_loc = c.feats.data_ptr(), K.LOC_DEVICE
     if args.table == "host":   # move the table to pinned, device-mapped host memory; misses then cross PCIe
         nbytes = V * F * 4
         c.host_table = L.host_alloc_space64(nbytes)
@@ -230,34 +297,118 @@ def worker(args):
     make_seeds(c)
     c.gen_s = time.time() - t0
 
-    head = run_leg(c, unified=(args.cache == "unified"), headline=True)
 
-    line = None
-    if rank == 0:
-        line = headline_line(c, head)
-    second = None
-    if world > 1 and args.cache == "replicated" and not args.no_unified_leg and args.table == "device":
-        second = guarded_unified_leg(c, line)
-    if line is not None and second is not None:
-        line["unified_cache"] = second
+class LegGuard:
+    """Watchdog of the legs that run after the headline leg.  A leg that raises is reported inside the line ("legs_failed" at
+    the top level + an "error" object in its place) and the run goes on.  A leg that does not come back within its timeout
+    (a collective or an IPC import that never returns) cannot be recovered from inside the process: rank 0 prints the line it
+    has -- headline included, the leg named in "legs_failed" with the Python stack it was stuck in -- and EVERY rank leaves with
+    exit code LEG_HUNG_EXIT.  The timer of a rank stays armed through the agreement all-gather and the barrier behind the leg,
+    so a rank that finished cannot be left waiting in a collective for one that hangs: its own timer ends it too."""
 
-    # measured streaming-copy rate of this box (float4 copy kernel sized like the gather, read + write bytes)
-    if rank == 0 and line.get("roofline") is not None:
-        line["roofline"]["measured_copy_GBps"] = measure_copy(c)
-    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
-        feats = c.feats
-        if c.host_table is not None:   # the table already is host memory: view it, no copy
-            import ctypes
-            feats = np.ctypeslib.as_array(ctypes.cast(c.host_table, ctypes.POINTER(ctypes.c_float)), shape=(V, F))
+    def __init__(self, c, line):
+        self.c, self.line = c, line
+        self.partial = None        # what a leg has measured so far (printed if a later part of it hangs)
+
+    def run(self, name, timeout, fn):
+        import faulthandler
+        import traceback
+        c, line = self.c, self.line
+        main_thread = threading.main_thread().ident
+        self.partial = None
+
+        def fire():
+            try:
+                msg = f"did not finish within {timeout:.0f} s"
+                stack = "".join(traceback.format_stack(sys._current_frames().get(main_thread)))[-1500:]
+                if c.rank == 0:
+                    line["legs_failed"].append({"leg": name, "error": msg, "hung": True, "stuck_at": stack})
+                    part = self.partial
+                    err = dict(part, error=msg) if isinstance(part, dict) else {"error": msg}
+                    if name in ("unified_cache",):
+                        line[name] = err
+                    else:
+                        line["extra_legs"][name] = err
+                    print(json.dumps(line), flush=True)
+                faulthandler.dump_traceback(file=sys.stderr)
+            finally:
+                os._exit(LEG_HUNG_EXIT)
+        timer = threading.Timer(timeout, fire)
+        timer.daemon = True
+        timer.start()
         try:
-            line["cpu_baseline"] = run_cpu_baseline(args, spec, c.indptr, c.indices, feats, c.mine, c.my_labels, B, fan, c.steps_avail)
-        except Exception as ex:   # noqa: BLE001 -- reported baseline only: never lose the headline line over it
-            line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+            ok, res = True, None
+            try:
+                res = fn()
+            except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
+                ok, res = False, {"error": repr(ex)[:300]}
+            # every rank must agree that the leg worked before its numbers are believed
+            flags = c.D.allgather_object((ok, None if ok else res["error"]), c.world)
+            bad = [(i, e) for i, (f, e) in enumerate(flags) if not f]
+            if bad:
+                if ok:
+                    res = {"error": "failed on rank(s) %s" % [i for i, _ in bad]}
+                line["legs_failed"].append({"leg": name, "error": "; ".join("rank %d: %s" % (i, e) for i, e in bad)[:600], "hung": False})
+            c.D.barrier(c.world)
+            return res
+        finally:
+            timer.cancel()
+
+
+def extra_leg_names(c):
+    a = c.args
+    if a.extra_legs == "none":
+        return []
+    if a.extra_legs == "auto":
+        default = (a.workload == "papers100M" and a.task == "node" and a.cache == "replicated" and a.table == "device")
+        return ["lp", "uk_union"] if (c.world > 1 and default) else []
+    names = [x for x in a.extra_legs.split(",") if x]
+    bad = [x for x in names if x not in ("lp", "uk_union")]
+    if bad:
+        raise SystemExit("bench.py: unknown --extra-legs %s" % bad)
+    return sorted(names)        # lp first: it re-uses the headline graph, uk_union replaces it
+
+
+def extra_leg(c, name):
+    """BASELINE.json configs 5 (lp) and 4 (uk_union) in the processes of this run."""
+    import copy
+    a = copy.copy(c.args)
+    c2 = copy.copy(c)
+    c2.args = a
+    a.min_time = c.args.extra_min_time
+    if name == "lp":
+        # lp_sage.py:87-90: [src | pos | neg] seed thirds; triples dealt to the ranks by src % N; the graph is the headline's
+        a.task, a.batch = "lp", (c.B // 3) * 3
+        c2.B = a.batch
+        make_seeds(c2)
+        leg = run_leg(c2, unified=False, headline=False, min_time=a.min_time)
+        return leg_summary(c2, leg, "link-prediction seed batches [src | pos | neg] (lp_sage.py:87-90) on the headline graph, replicated tables")
+    # uk_union: legion_server.py:23-37 shape, 2-hop GCN fan-out; the hottest 30 % of the adjacency rows as partitioned CSR fragments
+    # over the N-GPU clique (GPU_Memory_Graph_Storage.cu:98-133), 10 % of the feature rows in the unified cache, the rest from the
+    # HBM replica (a pinned-host backing table of 137 GB per process is not attempted here; tests/test_gpu_full_shape.py covers it)
+    a.workload, a.fanout, a.task, a.topo_frac, a.cache_frac, a.no_exchange_leg = "uk-union", "25,10", "node", 0.3, 0.10, True
+    c2.fan, c2.H = [25, 10], 2
+    load_workload(c2, "uk-union")
+    for k in ("spec", "pitch", "indptr", "indices", "feats", "E", "feat_ptr", "feat_loc", "host_table", "mine", "my_labels", "n_mine", "steps_avail", "gen_s"):
+        setattr(c, k, getattr(c2, k))      # the headline graph is gone: later legs see this one
+    leg = run_leg(c2, unified=True, headline=False, min_time=a.min_time)
+    return leg_summary(c2, leg, f"uk-union-shape graph, CSR sharded over the {c.world}-GPU clique (30 % of the adjacency rows in partitioned "
+                                "fragments) + 10 % of the feature rows in the unified cache, misses from the HBM replica")
+
+
+def leg_summary(c, leg, what):
+    args, F = c.args, c.spec.F
+    el = leg["elapsed"]
+    g = leg["g_ms"]
+    reps = max(1, len(g) // args.steps)
+    ach = float(leg["gather_bytes"].sum()) * reps / (g.sum() * 1e-3) / 1e9 if len(g) else None
+    return {"what": what, "value": round(leg["job_edges"] / el, 1), "unit": "edges/s", "ms_per_step": round(el / args.steps * 1e3, 4),
+            "feature_GBps": round(leg["job_nodes"] * 4 * F / el / 1e9, 2), "batch": c.B, "fanout": c.fan, "V": c.spec.V, "E": c.E, "F": F,
+            "edges_per_batch": round(leg["job_edges"] / (args.steps * c.world), 1),
+            "unique_nodes_per_batch": round(leg["job_nodes"] / (args.steps * c.world), 1),
+            "gather_avg_launch_us": round(float(g.mean()) * 1e3, 2) if len(g) else None,
+            "gather_frac_of_hbm_peak": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
+            "windows": len(leg["windows"]), "graph_gen_s": round(c.gen_s, 2), **(leg["cache_info"] or {}), **(leg["xgmi"] or {})}
 
 
 def make_seeds(c):
@@ -297,41 +448,12 @@ def make_seeds(c):
     c.steps_avail = max(1, (c.n_mine - 1) // c.B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
 
 
-def guarded_unified_leg(c, line):
-    """The unified-cache leg must never cost the headline: a failure is reported inside the line, and if the leg
-    does not finish in time (an IPC import that never returns, profiles/r01_unified_ipc_notes.md) rank 0 prints
-    the headline without it and every rank leaves."""
-    def fire():
-        if c.rank == 0:
-            msg = f"did not finish within {c.args.unified_timeout:.0f} s"
-            part = getattr(c, "partial_unified", None)
-            line["unified_cache"] = dict(part, exchange_variant={"error": msg}) if part else {"error": msg}
-            print(json.dumps(line), flush=True)
-        os._exit(0)      # every rank: the line rank 0 printed carries the error; a non-zero rank would fail the whole launch
-    timer = threading.Timer(c.args.unified_timeout, fire)
-    timer.daemon = True
-    timer.start()
-    try:
-        ok, res = True, None
-        try:
-            leg = run_leg(c, unified=True, headline=False)
-            res = unified_summary(c, leg)
-        except Exception as ex:  # noqa: BLE001
-            ok, res = False, {"error": repr(ex)[:300]}
-        # every rank must agree that the leg worked before its numbers are believed
-        flags = c.D.allgather_object(ok, c.world)
-        if not all(flags) and ok:
-            res = {"error": "failed on rank(s) %s" % [i for i, f in enumerate(flags) if not f]}
-        return res
-    finally:
-        timer.cancel()
-
-
-def run_leg(c, unified, headline):
+def run_leg(c, unified, headline, min_time=None):
     """W warm-up steps, then R windows of exactly K timed steps (barrier + synchronize on both sides of every
     window, max over ranks per window, median over windows).  Returns the raw numbers of the leg."""
     import torch
     args, K, D, L = c.args, c.K, c.D, c.L
+    min_time = args.min_time if min_time is None else min_time
     rank, world, dev = c.rank, c.world, c.dev
     V, F, B, fan, H = c.spec.V, c.spec.F, c.B, c.fan, c.H
     G = world if unified else 1          # logical GPUs of the clique this process knows about
@@ -347,7 +469,7 @@ def run_leg(c, unified, headline):
     depth = 2      # the reference's PIPELINE_DEPTH; the serial schedule only uses pipe 0
     eng = K.Engine(c.indptr.data_ptr(), c.indices.data_ptr(), c.feat_ptr, V, F, seeds, B, fan, G=G,
                    csr_location=K.LOC_DEVICE, features_location=c.feat_loc, E=c.E, pipeline_depth=depth,
-                   local_devs=[me], train_step=max(1, args.presc_steps))
+                   local_devs=[me], train_step=max(1, args.presc_steps), features_pitch=c.pitch if c.feat_loc == K.LOC_DEVICE else 0)
     eng.alloc_features()
     cache_info = None
     if unified:
@@ -458,13 +580,13 @@ def run_leg(c, unified, headline):
         L.d_stream_sync(gstream2)
         torch.cuda.synchronize()
 
-    def window(**kw):
+    def window(timed=True, **kw):
         """EXACTLY K steps between (synchronize + barrier) and (synchronize + barrier)."""
         drain()
         D.barrier(world)
         t_start = time.perf_counter()
         for i in range(K_steps):
-            step(W + i, timed_idx=i, **kw)
+            step(W + i, timed_idx=i if timed else None, **kw)
         drain()
         el = time.perf_counter() - t_start
         D.barrier(world)
@@ -488,7 +610,7 @@ def run_leg(c, unified, headline):
         g_ms += [L.d_event_elapsed_ms(a, b) for a, b in ev]
     # every rank runs the same number of windows: R from the slowest rank's first window
     first_max, _ = D.aggregate(windows[0], [0.0], world, device=dev)
-    reps = int(min(args.max_reps, max(1, -(-args.min_time // max(first_max, 1e-6)))))
+    reps = int(min(args.max_reps, max(1, -(-min_time // max(first_max, 1e-6)))))
     for _ in range(reps - 1):
         windows.append(window())
         if not per_level:
@@ -519,19 +641,18 @@ def run_leg(c, unified, headline):
                u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, graph=None,
                xgmi=None, exchange=None, xgmi_hw=xgmi_hw)
 
-    # the other schedule on the very same K batches (reported beside the headline, never instead of it)
+    # the other schedule on the very same K batches, in windows like the headline (median window): with --pipeline serial this
+    # is the two-stream schedule the `legion` server runs (gather of batch i on stream 1 while batch i+1 is sampled)
     if headline and not per_level and not intra and not args.headline_only:
-        drain()
-        D.barrier(world)
-        t_alt = time.perf_counter()
-        for i in range(K_steps):
-            step(W + i, overlap=not overlap)
-        drain()
-        alt_elapsed = time.perf_counter() - t_alt
-        D.barrier(world)
-        alt_max, _ = D.aggregate(alt_elapsed, [0.0], world, device=dev)
+        alt_w = [window(timed=False, overlap=not overlap)]
+        a_first, _ = D.aggregate(alt_w[0], [0.0], world, device=dev)
+        a_reps = int(min(args.max_reps, max(1, -(-(min_time / 2) // max(a_first, 1e-6)))))
+        for _ in range(a_reps - 1):
+            alt_w.append(window(timed=False, overlap=not overlap))
+        alt_max = float(np.median(D.aggregate_max_vec(alt_w, world, device=dev)))
         leg["alt"] = {"pipeline": "serial" if overlap else "overlap", "ms_per_step": round(alt_max / K_steps * 1e3, 4),
-                      "value": round(job_edges / alt_max, 1), "unit": "edges/s",
+                      "value": round(job_edges / alt_max, 1), "unit": "edges/s", "windows": len(alt_w),
+                      "feature_GBps": round(job_nodes * 4 * F / alt_max / 1e9, 2),
                       "pipeline_frac": round(job_bytes / alt_max / 1e9 / (HBM_PEAK_GBPS * world), 4)}
 
     # the serial schedule again, recorded once as a hipGraph and replayed with one launch per batch (same K batches)
@@ -556,7 +677,8 @@ def run_leg(c, unified, headline):
     if unified and not per_level:
         leg["xgmi"] = unified_cache_traffic(c, eng, me, cache_info, float(leg["g_ms"].mean()))
     if unified and not headline and world > 1 and not args.no_exchange_leg:
-        c.partial_unified = unified_summary(c, leg)      # what the watchdog prints if the exchange leg never comes back
+        if getattr(c, "guard", None) is not None:
+            c.guard.partial = unified_summary(c, leg)    # what the watchdog prints if the exchange leg never comes back
         try:
             leg["exchange"] = exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes)
         except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
@@ -570,54 +692,81 @@ def run_leg(c, unified, headline):
 
 def exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes):
     """The same K batches with the owner-computes exchange gather (legion-1_amd/exchange.py) instead of in-kernel peer loads:
-    per batch one all-to-all of request lists and one of rows over RCCL.  Lock-step and host-synchronous (the split sizes of the
-    all-to-all are read back every batch), so this is one timed window of K steps."""
+    per batch one all-to-all of request lists and one of rows over RCCL, pre-allocated buffers, ONE host synchronisation per
+    batch (the split sizes), nothing waited for at the end of a batch.  Timed in windows of K steps like every other leg."""
     import torch
     from legion1_amd.exchange import ExchangeGather
     args, K, D, L = c.args, c.K, c.D, c.L
     world, dev, B, fan, H, F = c.world, c.dev, c.B, c.fan, c.H, c.spec.F
     xg = ExchangeGather(K, eng, me, world, F, dev, eng.num_ids)
     K_steps, W = args.steps, args.warmup
-    t_x = [0.0]
+    ev = [(L.d_event_create(), L.d_event_create()) for _ in range(K_steps)]
+    info = [None]
 
-    def step(i):
+    def step(i, timed_idx=None):
         L.GPUMemoryPool_SetCurrentPipe(pool, 0)
         L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
         L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, i % steps_avail, me, me, K.TRAINMODE)
         for h in range(H):
             L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
-        t0 = time.perf_counter()
-        info = xg.run(stream, pool)
-        t_x[0] += time.perf_counter() - t0
-        return info
+        if timed_idx is not None:
+            L.d_event_record(ev[timed_idx][0], stream)
+        info[0] = xg.run(stream, pool)          # leaves `stream` waiting for the scatter
+        if timed_idx is not None:
+            L.d_event_record(ev[timed_idx][1], stream)
 
-    for i in range(min(W, 2)):
+    def drain():
+        L.d_stream_sync(stream)
+        xg.wait()
+        torch.cuda.synchronize()
+
+    def window():
+        drain()
+        D.barrier(world)
+        t0 = time.perf_counter()
+        for i in range(K_steps):
+            step(W + i, timed_idx=i)
+        drain()
+        el = time.perf_counter() - t0
+        D.barrier(world)
+        return el
+
+    for i in range(max(W, 2)):      # also grows the row buffers to their steady-state size
         step(i)
-    torch.cuda.synchronize()
-    D.barrier(world)
-    t_x[0] = 0.0
+    drain()
+    allocs_before = xg.allocations
     xc = None
     if c.rank == 0:
         import legion1_amd.xgmi_counters as xc
-    x0 = xc.read() if xc else None
-    t0 = time.perf_counter()
-    for i in range(K_steps):
-        info = step(W + i)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    hw = xc.rate(x0, xc.read(), el, world) if xc else None
-    D.barrier(world)
-    el_max, (rows_req, x_s) = D.aggregate(el, [info["rows_requested"], t_x[0]], world, device=dev)
-    xg.close()
-    out = {"what": "owner-computes exchange: request lists and rows over one RCCL all-to-all each per batch, owners gather from their own HBM",
+    x0, t_x0 = (xc.read(), time.perf_counter()) if xc else (None, 0.0)
+    wins = [window()]
+    x_ms = [L.d_event_elapsed_ms(a, b) for a, b in ev]
+    first, _ = D.aggregate(wins[0], [0.0], world, device=dev)
+    reps = int(min(args.max_reps, max(1, -(-args.extra_min_time // max(first, 1e-6)))))
+    for _ in range(reps - 1):
+        wins.append(window())
+        x_ms += [L.d_event_elapsed_ms(a, b) for a, b in ev]
+    hw = xc.rate(x0, xc.read(), time.perf_counter() - t_x0, world) if xc else None
+    el_max = float(np.median(D.aggregate_max_vec(wins, world, device=dev)))
+    x_s = float(np.mean(x_ms)) * 1e-3                                   # HIP-event time of one exchange gather on this rank
+    _, (rows_req, x_sum) = D.aggregate(0.0, [info[0]["rows_requested"], x_s], world, device=dev)
+    out = {"what": "owner-computes exchange: request lists and rows over one RCCL all-to-all each per batch, owners gather from their own HBM; "
+                   "buffers allocated once, one host synchronisation per batch (the split sizes), windows of K steps",
            "ms_per_step": round(el_max / K_steps * 1e3, 4), "value": round(job_edges / el_max, 1), "unit": "edges/s",
-           "feature_GBps": round(job_nodes * 4 * F / el_max / 1e9, 2), "exchange_ms_per_step": round(x_s / world / K_steps * 1e3, 4),
+           "feature_GBps": round(job_nodes * 4 * F / el_max / 1e9, 2), "windows": len(wins),
+           "exchange_gather_ms_per_step": round(x_sum / world * 1e3, 4),
+           "host_syncs_per_batch": round(xg.host_syncs_per_batch, 3), "gloo_staging_syncs_per_batch": round(xg.staging_syncs / max(1, xg.batches), 3),
+           "allocations_in_timed_windows": xg.allocations - allocs_before,
            "rows_requested_last_batch_per_gpu": round(rows_req / world, 1), "xgmi_hw_counters": hw}
-    rate = rows_req / world * 4 * F / max(x_s / world / K_steps, 1e-9) / 1e9     # rows received per GPU / time inside the exchange
+    rate = rows_req / world * 4 * F / max(x_sum / world, 1e-9) / 1e9     # rows received per GPU / HIP-event time of the exchange gather
     if c.shared_device:
         out["a2a_rows_GBps_same_device"] = round(rate, 1)
     else:
         out.update({"xgmi_recv_GBps_per_gpu": round(rate, 1), "xgmi_frac_of_peak": round(rate / XGMI_PEAK_GBPS, 4)})
+    xg.close()
+    for a, b in ev:
+        L.d_event_destroy(a)
+        L.d_event_destroy(b)
     return out
 
 
@@ -695,10 +844,12 @@ def headline_line(c, leg):
                                + ("+ features resident in HBM" if args.table == "device" else "in HBM, features in pinned host memory (PCIe zero-copy)")
                                + (" (Kg=1 replicas)" if not unified else f", unified feature cache over the {world}-GPU clique")
                                + ("" if args.skew == 205 else f", neighbour skew {args.skew}/256"),
-                   "V": spec.V, "E": c.E, "F": F, "batch": B, "fanout": fan, "gather": args.gather,
+                   "V": spec.V, "E": c.E, "F": F, "row_pitch_floats": c.pitch, "batch": B, "fanout": fan, "gather": args.gather,
                    "pipeline": args.pipeline if args.gather == "all" else "serial", "seeds_per_rank": c.n_mine, "task": args.task,
                    "parallelism": f"dp{world} (seed shards tid % {world}, no data-path collective)"},
-        "timing": {"windows": len(leg["windows"]), "steps_per_window": K_steps, "window_ms": leg["windows"],
+        "timing": {"windows": len(leg["windows"]), "steps_per_window": K_steps,
+                   "window_ms_min_median_max": [min(leg["windows"]), round(float(np.median(leg["windows"])), 4), max(leg["windows"])],
+                   "window_ms_first_32": leg["windows"][:32],
                    "reported": "median window, max over ranks per window"},
         "feature_GBps": round(leg["job_nodes"] * 4 * F / el / 1e9, 2),
         "batches_per_s": round(K_steps * world / el, 2),
@@ -707,8 +858,15 @@ def headline_line(c, leg):
         "sampler_algorithmic_bytes_per_batch": int(leg["samp_bytes"].mean()),   # 20 N_h + 28 E_h + 8 U_h summed over the hops
         "gather_algorithmic_bytes_per_batch": int(leg["gather_bytes"].mean()),
         "graph_gen_s": round(c.gen_s, 2),
+        # the two-stream schedule the `legion` server runs (gather of batch i on stream 1 while batch i+1 is sampled), same
+        # batches, median of its own windows: the best number the pipeline produces; `value` stays the serial schedule, whose
+        # kernels run alone and give the clean per-kernel roofline
+        "value_overlap": (leg["alt"] or {}).get("value") if (leg["alt"] or {}).get("pipeline") == "overlap" else None,
+        "ms_per_step_overlap": (leg["alt"] or {}).get("ms_per_step") if (leg["alt"] or {}).get("pipeline") == "overlap" else None,
         "alt_schedule": leg["alt"],
         "graph_replay": leg["graph"],
+        "legs_failed": [],          # legs after the headline that raised or hung (N > 1): [] = every leg in this line is valid
+        "extra_legs": {},
         "cache": {"mode": "unified" if unified else "replicated", **(leg["cache_info"] or {}), **(leg["xgmi"] or {})},
         "roofline": roofline_of(c, leg),
         "cpu_baseline": None,
@@ -824,8 +982,10 @@ def measure_copy(c):
 
 
 def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan, steps_avail):
-    """The CPU oracle (reference semantics, scalar C, 1 thread) timed on the host cores on a bounded
-    sample of the SAME workload: the first few batches of rank 0's seed list."""
+    """The CPU side of the same workload on a bounded sample (the first batches of rank 0's seed list), --cpu-baseline-seconds
+    of CPU time in total: the oracle (reference semantics; scalar C, 1 thread = `value`, and its OpenMP run on all cores the
+    process may use) and DGL's CPU NeighborSampler (BASELINE.json config 1) if importable, else our own OpenMP implementation of
+    the same semantics -- labelled as such, never as DGL."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch
     import oracle as O
@@ -834,35 +994,50 @@ def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan
     h_indices = indices.cpu().numpy()
     with_feat = not args.no_cpu_features
     h_feats = (feats if isinstance(feats, np.ndarray) else feats.cpu().numpy()) if with_feat else None
+    if h_feats is not None and h_feats.shape[1] != spec.F:      # padded HBM rows: the CPU side reads the dense layout
+        h_feats = np.ascontiguousarray(h_feats[:, :spec.F])
     h_ids = mine.cpu().numpy()
     h_lab = my_labels.cpu().numpy()
     copy_s = time.time() - t0
-    runner = O.OracleRunner(h_indptr, h_indices, h_feats, spec.V, spec.F, B, fan, with_features=with_feat)
-    edges, n, t_used = 0, 0, 0.0
+    total = float(args.cpu_baseline_seconds)
+    budget = {"serial": 0.4 * total, "omp": 0.2 * total, "dgl": 0.4 * total}
     H = len(fan)
-    while t_used < args.cpu_baseline_seconds and n < min(steps_avail, 64):
-        t1 = time.perf_counter()
-        res = runner.run_batch(h_ids, h_lab, n)
-        t_used += time.perf_counter() - t1
-        edges += int(res["ec"][2 + H])
-        n += 1
-    # second reported baseline: DGL's CPU NeighborSampler (BASELINE.json config 0) if importable, else our
-    # own OpenMP implementation of the same semantics -- labelled as such, never as DGL
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    runner = O.OracleRunner(h_indptr, h_indices, h_feats, spec.V, spec.F, B, fan, with_features=with_feat)
+
+    def timed(fn, seconds):
+        edges, n, used = 0, 0, 0.0
+        while used < seconds and n < min(steps_avail, 64):
+            t1 = time.perf_counter()
+            edges += fn(n)
+            used += time.perf_counter() - t1
+            n += 1
+        return edges, n, used
+
+    edges, n, t_used = timed(lambda i: int(runner.run_batch(h_ids, h_lab, i)["ec"][2 + H]), budget["serial"])
+    smp = O.DglSemanticsSampler(h_indptr, h_indices, h_feats, spec.V, spec.F, B, fan)      # also tells the OpenMP thread count
+    omp = None
+    try:
+        e1, n1, t1 = timed(lambda i: int(runner.run_batch(h_ids, h_lab, i, omp=True)["ec"][2 + H]), budget["omp"])
+        omp = {"value": round(e1 / t1, 1), "unit": "edges/s", "cores": smp.threads, "kind": "port",
+               "sample": f"{n1} batches, oracle/legion_oracle.c lo_run_batch_omp: draws, COO offsets and row copies parallel, "
+                         "the order-defining compaction serial (byte-identical to the 1-thread run)", "seconds": round(t1, 2)}
+    except Exception as ex:   # noqa: BLE001
+        omp = {"error": repr(ex)[:200]}
+    # DGL's CPU NeighborSampler if importable, else our own OpenMP implementation of the same semantics
     dgl_like = None
     try:
-        budget = min(10.0, args.cpu_baseline_seconds)
         try:
             import dgl  # noqa: F401
-            dgl_like = run_dgl_baseline(dgl, torch, h_indptr, h_indices, h_feats, h_ids, B, fan, budget)
+            dgl_like = run_dgl_baseline(dgl, torch, h_indptr, h_indices, h_feats, h_ids, B, fan, budget["dgl"])
         except ImportError:
-            smp = O.DglSemanticsSampler(h_indptr, h_indices, h_feats, spec.V, spec.F, B, fan)
-            e2, n2, t2 = 0, 0, 0.0
-            while t2 < budget and n2 < min(steps_avail, 64):
-                t1 = time.perf_counter()
-                _, e = smp.run_batch(h_ids[n2 * B:(n2 + 1) * B], rng_seed=n2 + 1, gather=with_feat)
-                t2 += time.perf_counter() - t1
-                e2 += e
-                n2 += 1
+            e2, n2, t2 = timed(lambda i: int(smp.run_batch(h_ids[i * B:(i + 1) * B], rng_seed=i + 1, gather=with_feat)[1]), budget["dgl"])
             dgl_like = {"value": round(e2 / t2, 1), "unit": "edges/s", "cores": smp.threads,
                         "kind": "DGL-semantics CPU sampler (own OpenMP implementation; dgl not installed)",
                         "sample": f"{n2} batches, uniform w/o replacement + to_block per layer + index_select"
@@ -870,10 +1045,14 @@ def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan
     except Exception as ex:  # the headline CPU number must not depend on this leg
         dgl_like = {"error": repr(ex)}
     return {"value": round(edges / t_used, 1), "unit": "edges/s", "cores": 1, "kind": "port",
-            "dgl_semantics": dgl_like,
+            "openmp": omp, "dgl_semantics": dgl_like,
             "sample": f"{n} batches (batch {B}, fan-out {fan}) of the same workload, oracle/legion_oracle.c single thread"
                       + ("" if with_feat else ", sampler+COO only (no feature gather)"),
-            "seconds": round(t_used, 2), "host_copy_s": round(copy_s, 1), "host_cores_available": os.cpu_count()}
+            "seconds": round(t_used, 2), "host_copy_s": round(copy_s, 1), "cpu_model": cpu_model,
+            "host_cores_available": os.cpu_count(), "host_cores_in_affinity_mask": affinity,
+            "threads_note": "OpenMP legs use omp_get_max_threads(), which follows the affinity mask / cgroup quota of this process: "
+                            "on the GPU pool a one-GPU lease is pinned to a share of the host's hardware threads, so "
+                            "`cores` can be below host_cores_available"}
 
 
 def run_dgl_baseline(dgl, torch, indptr, indices, feats, ids, B, fan, budget):

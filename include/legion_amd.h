@@ -115,7 +115,14 @@ typedef struct LegionBuildInfo {
     /* train */
     int32_t epoch;
     int32_t raw_batch_size;
+    /* extension (after the reference's fields): floats between two rows of host_float_attrs; 0 = F (dense, the reference's
+     * file layout).  A caller that builds the table itself may pad rows to legion_row_pitch(F). */
+    int32_t float_attr_pitch;
 } LegionBuildInfo;
+/* Row pitch (in floats) the library gives the HBM copies it owns (table replicas, cache shards): F when a row is a whole
+ * number of 128-byte lines, else F rounded up to 32 floats (F = 100 -> 128: every 400-byte row read then starts on a line)
+ * -- unless $LEGION_ROW_PITCH=dense.  The trainer-facing feature buffer stays dense [n, F]. */
+int32_t legion_row_pitch(int32_t F);
 
 /* Where a table handed to Build() lives.  The reference always uses pinned host memory read
  * by the GPUs through UVA (GPUGraphStore.cu:264-265,315).  On 288 GB parts the whole table
@@ -281,6 +288,7 @@ int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle6
  * row r % ChunkRows of chunk r / ChunkRows.  Each chunk is exported / imported on its own. */
 int32_t GPUCache_ShardChunkCount(const GPUCache* c, int32_t dev_id);
 int32_t GPUCache_ShardChunkRows(const GPUCache* c, int32_t dev_id);
+int32_t GPUCache_ShardPitch(const GPUCache* c);   /* floats between two rows of a chunk: legion_row_pitch(F) */
 float* GPUCache_GetShardChunk(const GPUCache* c, int32_t dev_id, int32_t chunk);
 int GPUCache_ExportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, void* handle64);
 int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, const void* handle64);
@@ -326,10 +334,12 @@ void get_feature_kernel_all(void* strm_hdl, GPUCache* cache, GPUNodeStorage* nod
  * hipMemcpyPeer in the caller: legion-1_amd/exchange.py).  plan (requester): rows of the batch cached on another clique member are
  * listed per owner -- req_row[k] = row in the owner's shard, req_dst[k] = row of the batch, contiguous per owner, owner-major,
  * counts[j] = rows asked of clique member j (device int32[2 * LEGION_MAX_DEVICE], the second half is scratch) -- and every other
- * row (own shard, backing table) is gathered at once.  serve (owner): rows list[0..n) of this GPU's shard -> out[n x F].
+ * row (own shard, backing table) gets its source address.  local (requester): gathers those rows; runs on any stream behind the
+ * plan, e.g. while the counts travel to the host.  serve (owner): rows list[0..n) of this GPU's shard -> out[n x F].
  * scatter (requester): rows[k] -> feature row req_dst[k] of the current pipe.  All pointers are device pointers. */
 int legion_exchange_plan(void* stream, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id,
                          int32_t* req_row, int32_t* req_dst, int32_t* counts);
+int legion_exchange_local(void* stream, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id);
 void legion_exchange_serve(void* stream, GPUCache* cache, int32_t dev_id, const int32_t* list, int32_t n, float* out);
 void legion_exchange_scatter(void* stream, GPUMemoryPool* memorypool, const float* rows, const int32_t* req_dst, int32_t n, int32_t F);
 
@@ -444,6 +454,8 @@ void legion_synth_neighbors_skew(void* stream, int32_t* indices_out, int64_t e0,
 void legion_synth_lp_seeds(void* stream, int32_t* out, const int32_t* srcs, const int64_t* triple_no, int64_t n_triples,
                            int32_t batch_size, const int64_t* indptr, const int32_t* indices, int32_t V, uint32_t seed);
 void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F);
+/* the same values with `pitch` floats between two rows (LegionBuildInfo.float_attr_pitch); pad floats are not written */
+void legion_synth_features_pitched(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F, int32_t pitch);
 void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int32_t classes);
 void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, int32_t V, uint32_t M2, uint32_t C2, int32_t stride, int32_t phase);
 /* streaming-copy kernel used by bench.py to report the measured HBM peak */

@@ -34,6 +34,7 @@ class LegionBuildInfo(C.Structure):
         ("csr_node_index", vp), ("csr_dst_node_ids", vp), ("csr_location", i32),
         ("total_edge_num", i64), ("cache_edge_num", i64),
         ("epoch", i32), ("raw_batch_size", i32),
+        ("float_attr_pitch", i32),
     ]
 
 
@@ -55,6 +56,8 @@ _SIGS = {
     "legion_set_error_mode": (None, [C.c_int]),
     "legion_set_device_map": (None, [i32, i32]),
     "legion_physical_device": (i32, [i32]),
+    "legion_row_pitch": (i32, [i32]),
+    "GPUCache_HitSamplingDone": (None, [vp, i32, vp]),
     "legion_set_remote_device": (None, [i32, C.c_int]),
     "legion_is_remote_device": (C.c_int, [i32]),
     "d_alloc_space": (vp, [i64]),
@@ -143,6 +146,7 @@ _SIGS = {
     "GPUCache_ImportFeatureShard": (C.c_int, [vp, i32, vp]),
     "GPUCache_ShardChunkCount": (i32, [vp, i32]),
     "GPUCache_ShardChunkRows": (i32, [vp, i32]),
+    "GPUCache_ShardPitch": (i32, [vp]),
     "GPUCache_GetShardChunk": (vp, [vp, i32, i32]),
     "GPUCache_ExportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
     "GPUCache_ImportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
@@ -162,6 +166,7 @@ _SIGS = {
     "get_feature_kernel": (None, [vp, vp, vp, vp, i32, i32, C.c_int]),
     "get_feature_kernel_all": (None, [vp, vp, vp, vp, i32, C.c_int]),
     "legion_exchange_plan": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp]),
+    "legion_exchange_local": (C.c_int, [vp, vp, vp, vp, i32]),
     "legion_exchange_serve": (None, [vp, vp, i32, vp, i32, vp]),
     "legion_exchange_scatter": (None, [vp, vp, vp, vp, i32, i32]),
     "make_update_plan": (None, [vp, vp, vp, vp, i32, i32]),
@@ -203,6 +208,7 @@ _SIGS = {
     "legion_synth_neighbors_skew": (None, [vp, vp, i64, i64, i32, u32, u32, i32]),
     "legion_synth_lp_seeds": (None, [vp, vp, vp, vp, i64, i32, vp, vp, i32, u32]),
     "legion_synth_features": (None, [vp, vp, i64, i64, i32]),
+    "legion_synth_features_pitched": (None, [vp, vp, i64, i64, i32, i32]),
     "legion_synth_labels": (None, [vp, vp, i32, i32, i32]),
     "legion_synth_seed_ids": (None, [vp, vp, i64, i64, i32, u32, u32, i32, i32]),
     "legion_copy_f4": (None, [vp, vp, vp, i64]),
@@ -291,7 +297,7 @@ class Engine:
 
     def __init__(self, indptr, indices, features, V, F, seeds, batch_size, fanout, G=1,
                  csr_location=LOC_DEVICE, features_location=LOC_DEVICE, cache_memory=0, train_step=1, epoch=1,
-                 pipeline_depth=1, E=None, local_devs=None):
+                 pipeline_depth=1, E=None, local_devs=None, features_pitch=0):
         L = lib()
         # one process per GPU: the other members of the clique are remote (legion_set_remote_device)
         self.local_devs = list(range(int(G))) if local_devs is None else list(local_devs)
@@ -351,6 +357,7 @@ class Engine:
             setattr(self, key + "_num", nums)
         info.total_num_nodes, info.float_attr_len = self.V, self.F
         info.host_float_attrs, info.features_location = self.features_ptr, features_location
+        info.float_attr_pitch = int(features_pitch)        # 0 = dense rows; > F: the table was built with padded rows
         info.csr_node_index, info.csr_dst_node_ids, info.csr_location = self.indptr_ptr, self.indices_ptr, csr_location
         info.total_edge_num, info.cache_edge_num = self.E, 0
         info.epoch, info.raw_batch_size = epoch, self.batch_size

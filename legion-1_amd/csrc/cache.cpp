@@ -417,6 +417,8 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
     const int32_t V = noder->total_num_nodes;
     const int32_t F = noder->float_attr_len;
     const int Kg = c->Kg;
+    const int32_t pitch = legion_row_pitch(F);   // shard rows start on a 128-byte line (F = 100 -> 512-byte rows)
+    c->shard_pitch = pitch;
     c->chunk_shift.assign(c->Kc, 30);
     c->nchunks.assign(c->Kc, 1);
     // A shard is a list of chunk allocations (2^chunk_shift rows each, <= 1 GiB by default): a large single
@@ -426,7 +428,7 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
     for (int i = 0; i < c->Kc; i++) {
         const int32_t ncap = c->node_capacity[i], ecap = c->edge_capacity[i];
         int shift = 0;
-        while (shift < 30 && (2ll << shift) * F * (int64_t)sizeof(float) <= chunk_bytes) shift++;
+        while (shift < 30 && (2ll << shift) * pitch * (int64_t)sizeof(float) <= chunk_bytes) shift++;
         const int32_t rpc = 1 << shift;
         c->chunk_shift[i] = shift;
         c->nchunks[i] = ncap > 0 ? (ncap + rpc - 1) / rpc : 1;
@@ -450,8 +452,9 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
                 for (int q = 0; q < c->nchunks[i]; q++) {
                     const int32_t row0 = q * rpc, rows = std::min(rpc, ncap - row0);
                     float* chunk = nullptr;
-                    HIP_CHECK(hipMalloc(&chunk, (size_t)rows * F * sizeof(float)));
-                    launch_feat_fill_up(nullptr, row0, rows, F, chunk, noder->float_attrs, c->QF[i], Kg, j, V);
+                    HIP_CHECK(hipMalloc(&chunk, (size_t)rows * pitch * sizeof(float)));
+                    if (pitch != F) HIP_CHECK(hipMemsetAsync(chunk, 0, (size_t)rows * pitch * sizeof(float), nullptr));
+                    launch_feat_fill_up(nullptr, row0, rows, F, pitch, noder->float_attr_pitch, chunk, noder->float_attrs, c->QF[i], Kg, j, V);
                     c->shard_chunks[dev].push_back(chunk);
                 }
                 c->float_feature_cache[dev] = c->shard_chunks[dev][0];
@@ -480,6 +483,7 @@ int32_t GPUCache_ShardChunkRows(const GPUCache* c, int32_t dev_id)
     if (!c || dev_id < 0 || dev_id >= c->device_count || c->chunk_shift.empty()) return 0;
     return 1 << c->chunk_shift[dev_id / c->Kg];
 }
+int32_t GPUCache_ShardPitch(const GPUCache* c) { return c ? (c->shard_pitch > 0 ? c->shard_pitch : c->float_attr_len) : 0; }
 float* GPUCache_GetShardChunk(const GPUCache* c, int32_t dev_id, int32_t chunk)
 {
     if (!c || dev_id < 0 || dev_id >= c->device_count || chunk < 0 || chunk >= (int)c->shard_chunks[dev_id].size()) return nullptr;
@@ -501,7 +505,8 @@ int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk,
     {   // what the exporter allocated for this chunk: 2^shift rows (the last chunk may be shorter)
         const int Ki = dev_id / c->Kg;
         const int64_t rows = std::min<int64_t>(1ll << c->chunk_shift[Ki], std::max<int64_t>(1, c->node_capacity[Ki]));
-        if (!ipc_size_ok(rows * c->float_attr_len * (int64_t)sizeof(float), "ImportFeatureShardChunk")) return -1;
+        if (c->shard_pitch <= 0) c->shard_pitch = legion_row_pitch(c->float_attr_len);
+        if (!ipc_size_ok(rows * c->shard_pitch * (int64_t)sizeof(float), "ImportFeatureShardChunk")) return -1;
     }
     hipIpcMemHandle_t h;
     memcpy(&h, handle64, sizeof(h));

@@ -150,6 +150,9 @@ struct GatherArgs {
                                               // inside the gather (no cache)
     int32_t cache_capacity;                   // rows per GPU
     int32_t F;
+    int32_t table_pitch, shard_pitch;         // floats between two rows of the backing table / of a shard chunk (0: F, dense).
+                                              // HBM copies we own are laid out with a 128-byte-aligned pitch when F * 4 is not
+                                              // a multiple of 128 (F = 100: 512 bytes), so that every row read starts on a line
     int32_t total_num_nodes;
     const int32_t* sampled_ids;
     const int32_t* nc;
@@ -167,7 +170,7 @@ void launch_gather(hipStream_t s, const GatherArgs& a, int32_t rows_bound);
 void launch_exchange_plan(hipStream_t s, const GatherArgs& g, int32_t me, int32_t Kg, int32_t* slot, int32_t* counts,
                           int32_t* req_row, int32_t* req_dst, int32_t rows_bound);
 void launch_exchange_rows(hipStream_t s, bool scatter, const float* const* shard_chunks, int32_t chunk_shift, const int32_t* list,
-                          int32_t n, int32_t F, const float* in, float* out, int32_t out_rows);
+                          int32_t n, int32_t F, int32_t shard_pitch, const float* in, float* out, int32_t out_rows);
 void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_t hops, unsigned long long* access,
                     int32_t* max_ids, int32_t bound);
 void launch_rng_probe(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* k, int32_t n);
@@ -179,8 +182,9 @@ void launch_build_topo_map(hipStream_t s, int8_t* owner, int32_t* row, const int
                            int32_t Ki, int32_t V);
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n);
 void launch_fill_i8(hipStream_t s, int8_t* p, int8_t v, int64_t n);
-void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, float* chunk, const float* table,
-                         const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V);
+void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, int32_t chunk_pitch, int32_t table_pitch, float* chunk,
+                         const float* table, const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V);
+void launch_copy_rows_pitched(hipStream_t s, float* dst, int32_t dst_pitch, const float* src, int32_t src_pitch, int32_t F, int64_t rows);
 void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
                            const int64_t* indptr, int64_t* count_out);
 void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,
@@ -274,7 +278,9 @@ struct GPUGraphStorage {
 struct GPUNodeStorage {
     int32_t partition_count = 0, total_num_nodes = 0, float_attr_len = 0;
     float* float_attrs = nullptr;     // device-visible V x F table
+    int32_t float_attr_pitch = 0;     // floats between two rows of float_attrs (>= float_attr_len)
     std::vector<float*> replica_attrs; // HBM replicas per logical GPU (GPUNodeStorage_ReplicateToDevices)
+    int32_t replica_pitch = 0;        // ... of the replicas (legion_row_pitch)
     int32_t features_location = LEGION_LOC_HOST_PINNED;
     bool owns_features = false;
     std::vector<int32_t> training_set_num, validation_set_num, testing_set_num;
@@ -321,6 +327,7 @@ struct GPUCache {
     std::vector<std::vector<float*>> shard_chunks;   // per logical GPU: the shard's chunk allocations
     std::vector<float**> d_shard_tab;                // per LOCAL logical GPU: device table [Kg x nchunks]
     std::vector<int32_t> chunk_shift, nchunks;       // per clique
+    int32_t shard_pitch = 0;                         // floats between two rows of a shard chunk (legion_row_pitch(F))
     bool is_presc = true;
     bool capacity_forced = false;
     int32_t forced_node_capacity = 0, forced_edge_capacity = 0;

@@ -619,6 +619,7 @@ struct GatherKArgs {
     GatherArgs g;
     FastDiv div_c;   // / chunks-per-row
     FastDiv div_cap; // / cache_capacity
+    int32_t lpr_shift; // >= 0: every row owns 2^lpr_shift lanes (row-aligned layout, see k_gather); < 0: dense q / C
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -652,9 +653,9 @@ __global__ __launch_bounds__(kBlock) void k_row_ptrs(GatherKArgs a)
                 const uint32_t didx = fdiv((uint32_t)gidx[u], a.div_cap);
                 const uint32_t fidx = (uint32_t)gidx[u] - didx * (uint32_t)g.cache_capacity;
                 const float* chunk = g.shard_tab[didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
-                src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * g.F;
+                src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * (g.shard_pitch > 0 ? g.shard_pitch : g.F);
             } else if (id[u] >= 0 && g.table) {
-                src = g.table + (int64_t)(id[u] % g.total_num_nodes) * g.F;
+                src = g.table + (int64_t)(id[u] % g.total_num_nodes) * (g.table_pitch > 0 ? g.table_pitch : g.F);
             }
             g.row_ptr[r] = src;
         }
@@ -669,6 +670,10 @@ __global__ __launch_bounds__(kBlock) void k_row_ptrs(GatherKArgs a)
     if (g.hit_stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(g.hit_stats + 1, rows);
 }
 
+// Row layout of the flat work space: q -> (row, 16-byte chunk).  Dense (lpr_shift < 0): q / C, q % C -- a wave covers
+// 64 consecutive chunks whatever the row length.  Row-aligned (lpr_shift >= 0, chosen by the launcher when C is not a
+// divisor of 64, e.g. F = 100: C = 25): every row owns 2^lpr_shift lanes, the lanes >= C idle, so a wave always holds
+// whole rows and with a 128-byte-aligned source pitch every row read starts on a line.
 template <typename VT, int UNROLL, int NT>
 __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
 {
@@ -677,8 +682,10 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
     const int32_t off = g.off_idx < 0 ? 0 : g.nc[g.off_idx];
     const int32_t rows = g.nc[g.size_idx];
     const int32_t C = g.F / VEC;
-    const int64_t total = (int64_t)rows * C;
+    const int32_t lpr = a.lpr_shift;
+    const int64_t total = lpr >= 0 ? ((int64_t)rows << lpr) : (int64_t)rows * C;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t pitch = g.table_pitch > 0 ? g.table_pitch : g.F;   // floats between two rows of the backing table
     if (g.rows_seen && blockIdx.x == 0 && threadIdx.x == 0) *g.rows_seen = rows; // launch-size feedback for later batches
     for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 < total; q0 += stride * UNROLL) {
         const VT* src[UNROLL];
@@ -690,8 +697,15 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
             src[u] = nullptr;
             dsti[u] = 0;
             if (q < total) {
-                const uint32_t r = fdiv((uint32_t)q, a.div_c); // rows*C < 2^31 is checked by the launcher
-                const uint32_t ch = (uint32_t)q - r * (uint32_t)C;
+                uint32_t r, ch;
+                if (lpr >= 0) {
+                    r = (uint32_t)(q >> lpr);
+                    ch = (uint32_t)q & ((1u << lpr) - 1u);
+                    if ((int32_t)ch >= C) continue;
+                } else {
+                    r = fdiv((uint32_t)q, a.div_c); // rows*C < 2^31 is checked by the launcher
+                    ch = (uint32_t)q - r * (uint32_t)C;
+                }
                 if (g.dst_rows > 0 && off + (int32_t)r >= g.dst_rows) continue; // never write past the buffer
                 dsti[u] = ((int64_t)(off + (int32_t)r) * g.F) / VEC + ch;
                 if (g.row_ptr) { // resolved by k_row_ptrs
@@ -700,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
                     continue;
                 }
                 const int32_t id = g.sampled_ids[off + (int32_t)r]; // no cache: the backing table row (Kernels.cu:689)
-                if (id >= 0) src[u] = reinterpret_cast<const VT*>(g.table + (int64_t)(id % g.total_num_nodes) * g.F) + ch;
+                if (id >= 0) src[u] = reinterpret_cast<const VT*>(g.table + (int64_t)(id % g.total_num_nodes) * pitch) + ch;
             }
         }
 #pragma unroll
@@ -786,14 +800,14 @@ __global__ __launch_bounds__(kBlock) void k_exch_fill(ExchArgs a)
             const uint32_t fidx = (uint32_t)gidx - owner * (uint32_t)g.cache_capacity;
             if ((int32_t)owner == a.me) {
                 const float* chunk = g.shard_tab[owner * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
-                src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * g.F;
+                src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * (g.shard_pitch > 0 ? g.shard_pitch : g.F);
             } else {
                 const int32_t k = s_base[owner] + atomicAdd(&s_cnt[owner], 1);
                 a.req_row[k] = (int32_t)fidx;
                 a.req_dst[k] = r;
             }
         } else if (id >= 0 && g.table) {
-            src = g.table + (int64_t)(id % g.total_num_nodes) * g.F;
+            src = g.table + (int64_t)(id % g.total_num_nodes) * (g.table_pitch > 0 ? g.table_pitch : g.F);
         }
         g.row_ptr[r] = src;
     }
@@ -801,7 +815,7 @@ __global__ __launch_bounds__(kBlock) void k_exch_fill(ExchArgs a)
 // owner side: rows list[0..n) of this GPU's shard -> out[n x F]; requester side: rows[k] -> dst[req_dst[k]]
 template <typename VT, bool SCATTER>
 __global__ __launch_bounds__(kBlock) void k_exch_rows(const float* const* __restrict__ shard_chunks, int32_t chunk_shift,
-                                                      const int32_t* __restrict__ list, int32_t n, int32_t F,
+                                                      const int32_t* __restrict__ list, int32_t n, int32_t F, int32_t shard_pitch,
                                                       const float* __restrict__ in, float* __restrict__ out, FastDiv div_c,
                                                       int32_t out_rows)
 {
@@ -816,7 +830,7 @@ __global__ __launch_bounds__(kBlock) void k_exch_rows(const float* const* __rest
             const VT v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(in + (int64_t)k * F) + ch);
             __builtin_nontemporal_store(v, reinterpret_cast<VT*>(out + (int64_t)row * F) + ch);
         } else {
-            const float* src = shard_chunks[row >> chunk_shift] + (int64_t)(row & ((1 << chunk_shift) - 1)) * F;
+            const float* src = shard_chunks[row >> chunk_shift] + (int64_t)(row & ((1 << chunk_shift) - 1)) * shard_pitch;
             const VT v = __builtin_nontemporal_load(reinterpret_cast<const VT*>(src) + ch);
             __builtin_nontemporal_store(v, reinterpret_cast<VT*>(out + (int64_t)k * F) + ch);
         }
@@ -880,14 +894,23 @@ __global__ void k_build_topo_map(int8_t* owner, int32_t* row, const int32_t* QT,
     }
 }
 // FeatFillUp (GPUCache.cu:200-205): cache row r of clique GPU Ki = features of QF[r*Kg + Ki]
-__global__ void k_feat_fill_up(int32_t row0, int32_t rows, int32_t F, float* cache, const float* table,
-                               const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V)
+__global__ void k_feat_fill_up(int32_t row0, int32_t rows, int32_t F, int32_t chunk_pitch, int32_t table_pitch, float* cache,
+                               const float* table, const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V)
 {
     const int64_t n = (int64_t)rows * F;
     for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = row0 + i / F, t = r * Kg + Ki;
+        const int64_t lr = i / F, c = i % F, t = (row0 + lr) * Kg + Ki;
         if (t >= V) continue;
-        cache[i] = table[(int64_t)QF[t] * F + i % F];
+        cache[lr * chunk_pitch + c] = table[(int64_t)QF[t] * table_pitch + c];
+    }
+}
+// dense / pitched row copy (HBM replica of a table with a line-aligned row pitch)
+__global__ void k_copy_rows_pitched(float* dst, int32_t dst_pitch, const float* src, int32_t src_pitch, int32_t F, int64_t rows)
+{
+    const int64_t n = rows * F;
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / F, c = i % F;
+        dst[r * dst_pitch + c] = src[r * src_pitch + c];
     }
 }
 // GetNeighborCount (GPU_Memory_Graph_Storage.cu:14-20)
@@ -1088,7 +1111,18 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // cache chunks are hipMalloc'ed (256-byte aligned) and hold whole rows: F % 4 == 0 keeps rows 16-byte aligned
     bool vec4 = (g.F % 4 == 0) && (((uintptr_t)g.table | (uintptr_t)g.dst) % 16 == 0);
     const int C = vec4 ? g.F / 4 : g.F;
-    if ((int64_t)rows_bound * C >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
+    // row-aligned lane layout (see k_gather): only when a wave would otherwise straddle rows at odd offsets
+    const char* lpr_env = getenv("LEGION_GATHER_ROW_LANES");
+    const int lpr_mode = lpr_env ? atoi(lpr_env) : -1;   // -1 auto, 0 never, 1 always
+    a.lpr_shift = -1;
+    int lanes = C;
+    if (vec4 && C < 64 && (64 % C) != 0 && lpr_mode != 0) {
+        int sh = 0;
+        while ((1 << sh) < C) sh++;
+        // idle lanes cost issue slots, not bandwidth: worth it when at most ~1/4 of the lanes idle, or when forced
+        if (lpr_mode == 1 || (C * 4 >= (1 << sh) * 3)) { a.lpr_shift = sh; lanes = 1 << sh; }
+    }
+    if ((int64_t)rows_bound * lanes >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);
     // Tuned on MI355X (profiles/r01_gather_sweep.md): non-temporal loads and stores (rows are read once and
     // written once: keep them out of L2/MALL).
@@ -1106,9 +1140,9 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
         // (re-swept in round 2, profiles/r02_gather_grid_sweep.md: 1-4 iterations per lane and a 3-25 % margin all land
         // within the run-to-run spread of 323-342 us at the papers100M shape)
         const int64_t est = std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024);
-        grid = grid_for(est * C, kBlock * (g.table_on_host ? 1 : 3), 8192); // rows over PCIe: latency-bound, maximise lanes in flight
+        grid = grid_for(est * lanes, kBlock * (g.table_on_host ? 1 : 3), 8192); // rows over PCIe: latency-bound, maximise lanes in flight
     } else {
-        grid = grid_for((int64_t)rows_bound * C, kBlock, 512);
+        grid = grid_for((int64_t)rows_bound * lanes, kBlock, 512);
     }
     if (vec4) k_gather<v4f, 1, 2><<<grid, kBlock, 0, s>>>(a);
     else k_gather<float, 1, 2><<<grid, kBlock, 0, s>>>(a);
@@ -1133,20 +1167,21 @@ void launch_exchange_plan(hipStream_t s, const GatherArgs& g, int32_t me, int32_
     HIP_CHECK_LAST();
 }
 void launch_exchange_rows(hipStream_t s, bool scatter, const float* const* shard_chunks, int32_t chunk_shift, const int32_t* list,
-                          int32_t n, int32_t F, const float* in, float* out, int32_t out_rows)
+                          int32_t n, int32_t F, int32_t shard_pitch, const float* in, float* out, int32_t out_rows)
 {
     if (n <= 0 || F <= 0) return;
+    if (shard_pitch <= 0) shard_pitch = F;
     const bool vec4 = (F % 4 == 0) && (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
     const int C = vec4 ? F / 4 : F;
     if ((int64_t)n * C >= (1ll << 31)) { LEGION_ARG_ERROR("legion_exchange: rows*F exceeds 2^31 work items"); return; }
     const FastDiv dc((uint32_t)C);
     const int grid = grid_for((int64_t)n * C, kBlock * 2, 8192);
     if (scatter) {
-        if (vec4) k_exch_rows<v4f, true><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
-        else k_exch_rows<float, true><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
+        if (vec4) k_exch_rows<v4f, true><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, shard_pitch, in, out, dc, out_rows);
+        else k_exch_rows<float, true><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, shard_pitch, in, out, dc, out_rows);
     } else {
-        if (vec4) k_exch_rows<v4f, false><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
-        else k_exch_rows<float, false><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, in, out, dc, out_rows);
+        if (vec4) k_exch_rows<v4f, false><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, shard_pitch, in, out, dc, out_rows);
+        else k_exch_rows<float, false><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, shard_pitch, in, out, dc, out_rows);
     }
     HIP_CHECK_LAST();
 }
@@ -1203,11 +1238,18 @@ void launch_build_topo_map(hipStream_t s, int8_t* owner, int32_t* row, const int
     k_build_topo_map<<<grid_for((int64_t)capacity * Kg, 256), 256, 0, s>>>(owner, row, QT, capacity, Kg, Ki, V);
     HIP_CHECK_LAST();
 }
-void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, float* chunk, const float* table,
-                         const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V)
+void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, int32_t chunk_pitch, int32_t table_pitch, float* chunk,
+                         const float* table, const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V)
 {
     if (rows <= 0) return;
-    k_feat_fill_up<<<grid_for((int64_t)rows * F, 256), 256, 0, s>>>(row0, rows, F, chunk, table, QF, Kg, Ki, V);
+    k_feat_fill_up<<<grid_for((int64_t)rows * F, 256), 256, 0, s>>>(row0, rows, F, chunk_pitch > 0 ? chunk_pitch : F, table_pitch > 0 ? table_pitch : F,
+                                                                  chunk, table, QF, Kg, Ki, V);
+    HIP_CHECK_LAST();
+}
+void launch_copy_rows_pitched(hipStream_t s, float* dst, int32_t dst_pitch, const float* src, int32_t src_pitch, int32_t F, int64_t rows)
+{
+    if (rows <= 0 || F <= 0) return;
+    k_copy_rows_pitched<<<grid_for(rows * F, 256), 256, 0, s>>>(dst, dst_pitch, src, src_pitch, F, rows);
     HIP_CHECK_LAST();
 }
 void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t Ki, int32_t capacity, int32_t V,

@@ -151,7 +151,10 @@ static bool gather_args(GatherArgs& g, GPUCache* cache, GPUNodeStorage* noder, G
     if (F < 0) std::cout << "error feature len\n"; // Kernels.cu:719-721
     const int q = p->current_pipe;
     if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return false; }
-    g.table = (dev_id >= 0 && dev_id < noder->partition_count && noder->replica_attrs[dev_id]) ? noder->replica_attrs[dev_id] : noder->float_attrs;
+    const bool replica = dev_id >= 0 && dev_id < noder->partition_count && noder->replica_attrs[dev_id];
+    g.table = replica ? noder->replica_attrs[dev_id] : noder->float_attrs;
+    g.table_pitch = replica ? noder->replica_pitch : noder->float_attr_pitch;
+    g.shard_pitch = cache ? cache->shard_pitch : 0;
     g.table_on_host = g.table == noder->float_attrs && noder->features_location != LEGION_LOC_DEVICE;
     g.shard_tab = nullptr; g.chunk_shift = 30; g.nchunks = 1;
     g.feat_map = nullptr;
@@ -220,8 +223,9 @@ void get_feature_kernel_all(void* strm_hdl, GPUCache* cache, GPUNodeStorage* nod
 
 // ---- owner-computes exchange variant of the gather (SURVEY 5 option b), one process per GPU ---------------------------------
 // Step 1 on the requester.  Rows [0, nc[0]) of the batch: those cached on ANOTHER clique member are listed (req_row: row in the
-// owner's shard, req_dst: row of the batch; contiguous per owner, owner-major; counts[j] rows for clique member j); all other rows
-// (own shard, backing table) are gathered into the feature buffer right away.  counts: device int32[2 * LEGION_MAX_DEVICE].
+// owner's shard, req_dst: row of the batch; contiguous per owner, owner-major; counts[j] rows for clique member j); every other row
+// (own shard, backing table) gets its source address.  counts: device int32[2 * LEGION_MAX_DEVICE].  Nothing is gathered yet: the
+// caller reads the counts back while legion_exchange_local (step 1b, any stream behind this one) gathers the local rows.
 int legion_exchange_plan(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id,
                          int32_t* req_row, int32_t* req_dst, int32_t* counts)
 {
@@ -231,6 +235,17 @@ int legion_exchange_plan(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder,
     if (!gather_args(g, cache, noder, p, dev_id, -1, 0)) return -1;
     if (!g.feat_map || !g.row_ptr || !p->cache_search_buffer) { LEGION_ARG_ERROR("legion_exchange_plan: needs a filled unified cache"); return -1; }
     launch_exchange_plan((hipStream_t)strm_hdl, g, dev_id % cache->Kg, cache->Kg, p->cache_search_buffer, counts, req_row, req_dst, p->num_ids);
+    return error_pending() ? -1 : 0;
+}
+// Step 1b on the requester: gather the rows legion_exchange_plan resolved locally (own shard / backing table); the peers' rows
+// have no source and are skipped -- legion_exchange_scatter fills them in.
+int legion_exchange_local(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id)
+{
+    if (!noder || !cache || !pool_ready(memorypool, "legion_exchange_local")) return -1;
+    GPUMemoryPool* p = memorypool;
+    GatherArgs g;
+    if (!gather_args(g, cache, noder, p, dev_id, -1, 0)) return -1;
+    if (!g.row_ptr) { LEGION_ARG_ERROR("legion_exchange_local: needs a filled unified cache"); return -1; }
     g.row_ptr_ready = true;   // k_exch_fill resolved the local rows (and left the peers' rows without a source)
     g.hit_stats = nullptr;
     launch_gather((hipStream_t)strm_hdl, g, p->num_ids);
@@ -242,7 +257,7 @@ void legion_exchange_serve(void* strm_hdl, GPUCache* cache, int32_t dev_id, cons
     if (!cache || dev_id < 0 || dev_id >= cache->device_count || !cache->d_shard_tab[dev_id] || (n > 0 && (!list || !out))) { LEGION_ARG_ERROR("legion_exchange_serve: bad arguments"); return; }
     const int Ki = dev_id / cache->Kg, j = dev_id % cache->Kg;
     launch_exchange_rows((hipStream_t)strm_hdl, false, cache->d_shard_tab[dev_id] + (size_t)j * cache->nchunks[Ki], cache->chunk_shift[Ki], list, n,
-                         cache->float_attr_len, nullptr, out, 0);
+                         cache->float_attr_len, cache->shard_pitch, nullptr, out, 0);
 }
 // Step 3 on the requester: rows[k] (as the owners returned them, in request order) -> feature row req_dst[k] of the current pipe.
 void legion_exchange_scatter(void* strm_hdl, GPUMemoryPool* memorypool, const float* rows, const int32_t* req_dst, int32_t n, int32_t F)
@@ -250,7 +265,7 @@ void legion_exchange_scatter(void* strm_hdl, GPUMemoryPool* memorypool, const fl
     if (!pool_ready(memorypool, "legion_exchange_scatter")) return;
     float* dst = memorypool->float_features[memorypool->current_pipe];
     if (!dst || (n > 0 && (!rows || !req_dst))) { LEGION_ARG_ERROR("legion_exchange_scatter: bad arguments"); return; }
-    launch_exchange_rows((hipStream_t)strm_hdl, true, nullptr, 0, req_dst, n, F, rows, dst, memorypool->feature_rows);
+    launch_exchange_rows((hipStream_t)strm_hdl, true, nullptr, 0, req_dst, n, F, F, rows, dst, memorypool->feature_rows);
 }
 
 // make_update_plan, Kernels.cu:758-783

@@ -87,6 +87,12 @@ using namespace legion;
 extern "C" {
 
 const char* legion_version(void) { return "legion-amd 0.1.0 (gfx950)"; }
+int32_t legion_row_pitch(int32_t F)
+{
+    const char* e = getenv("LEGION_ROW_PITCH");
+    if (F <= 0 || (e && strcmp(e, "dense") == 0) || (F * 4) % 128 == 0) return F;
+    return (F + 31) / 32 * 32;
+}
 void legion_set_error_mode(int mode) { g_error_mode = mode; }
 const char* legion_last_error(void) { return t_last_error.c_str(); }
 void legion_clear_error(void) { t_last_error.clear(); }

@@ -360,10 +360,12 @@ void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
     n->partition_count = P;
     n->total_num_nodes = info->total_num_nodes;
     n->float_attr_len = info->float_attr_len;
+    n->float_attr_pitch = info->float_attr_pitch > info->float_attr_len ? info->float_attr_pitch : info->float_attr_len;
+    n->replica_pitch = 0;
     n->features_location = info->features_location;
     bool owns = false;
     n->float_attrs = info->host_float_attrs
-        ? adopt_table<float>(info->host_float_attrs, (int64_t)info->total_num_nodes * info->float_attr_len, info->features_location, &owns)
+        ? adopt_table<float>(info->host_float_attrs, (int64_t)info->total_num_nodes * n->float_attr_pitch, info->features_location, &owns)
         : nullptr;
     n->owns_features = owns;
     n->replica_attrs.assign(P, nullptr);
@@ -394,8 +396,33 @@ void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
 int64_t GPUNodeStorage_ReplicateToDevices(GPUNodeStorage* n)
 {
     if (!n || !n->float_attrs || n->features_location == LEGION_LOC_DEVICE) return 0;
-    replicate_table<float>(n->float_attrs, (int64_t)n->total_num_nodes * n->float_attr_len, n->partition_count, n->replica_attrs);
-    return (int64_t)n->total_num_nodes * n->float_attr_len * 4;
+    const int32_t F = n->float_attr_len, pitch = legion_row_pitch(F);
+    const int64_t V = n->total_num_nodes;
+    n->replica_pitch = pitch;
+    if (pitch == n->float_attr_pitch) {
+        replicate_table<float>(n->float_attrs, V * pitch, n->partition_count, n->replica_attrs);
+        return V * pitch * 4;
+    }
+    // the replica gets a line-aligned row pitch (legion_row_pitch): one pitched copy per distinct physical device
+    std::vector<std::pair<int, float*>> per_phys;
+    for (int p = 0; p < n->partition_count; p++) {
+        if (is_remote_device(p) || n->replica_attrs[p]) continue;
+        const int phys = physical_device(p);
+        float* have = nullptr;
+        for (auto& e : per_phys) if (e.first == phys) have = e.second;
+        if (!have) {
+            DeviceGuard guard(p);
+            HIP_CHECK(hipMalloc(&have, (size_t)V * pitch * sizeof(float)));
+            if (have) {
+                HIP_CHECK(hipMemset(have, 0, (size_t)V * pitch * sizeof(float)));
+                HIP_CHECK(hipMemcpy2D(have, (size_t)pitch * sizeof(float), n->float_attrs, (size_t)n->float_attr_pitch * sizeof(float),
+                                      (size_t)F * sizeof(float), (size_t)V, hipMemcpyDefault));
+            }
+            per_phys.emplace_back(phys, have);
+        }
+        n->replica_attrs[p] = have;
+    }
+    return V * pitch * 4;
 }
 
 void GPUNodeStorage_Finalize(GPUNodeStorage* n)

@@ -46,12 +46,13 @@ __global__ void k_synth_neighbors(int32_t* out, int64_t e0, int64_t n, uint32_t 
     }
 }
 
-__global__ void k_synth_features(float* out, int64_t v0, int64_t nrows, int32_t F)
+__global__ void k_synth_features(float* out, int64_t v0, int64_t nrows, int32_t F, int32_t pitch)
 {
     const int64_t n = nrows * F;
     for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const uint64_t h = sm64(S_FEAT + (uint64_t)(v0 * F + i));
-        out[i] = (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f - 0.5f; // 2^-24
+        // same values whatever the row pitch: element c of row r lands at r * pitch + c (pad floats are left as they are)
+        out[pitch == F ? i : (i / F) * pitch + i % F] = (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f - 0.5f; // 2^-24
     }
 }
 
@@ -168,7 +169,14 @@ void legion_synth_lp_seeds(void* stream, int32_t* out, const int32_t* srcs, cons
 void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F)
 {
     if (nrows <= 0) return;
-    k_synth_features<<<big_grid(nrows * F), 256, 0, (hipStream_t)stream>>>(out, v0, nrows, F);
+    k_synth_features<<<big_grid(nrows * F), 256, 0, (hipStream_t)stream>>>(out, v0, nrows, F, F);
+    HIP_CHECK_LAST();
+}
+void legion_synth_features_pitched(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F, int32_t pitch)
+{
+    if (nrows <= 0) return;
+    if (pitch < F) { LEGION_ARG_ERROR("legion_synth_features_pitched: pitch < F"); return; }
+    k_synth_features<<<big_grid(nrows * F), 256, 0, (hipStream_t)stream>>>(out, v0, nrows, F, pitch);
     HIP_CHECK_LAST();
 }
 void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int32_t classes)

@@ -656,3 +656,77 @@ void lo_run_batch(lo_batch_ctx *c, const int32_t *all_ids, const int32_t *all_la
     }
     free(ip); free(ix);
 }
+
+/* ------------------------------------------------------------------------- */
+/* The same batch with OpenMP ("reference-      */
+/* semantics CPU oracle timed single-thread and OpenMP").  Resident form only  */
+/* (whole CSR, no caches, train mode).  Per hop:                               */
+/*   phase 1, parallel over slots: the draw of kernel_random_sampler_2         */
+/*            (Kernels.cu:375-411) -- source row, degree, Thrust discard(idx), */
+/*            neighbour -- parked in cand[idx] (-1: no edge);                  */
+/*   phase 2, SERIAL in ascending slot order: bitmap test-and-set, node and    */
+/*            edge append (:413-447) -- this is what fixes the canonical order; */
+/*   phase 3, parallel over edges: construct_graph (:450-463);                 */
+/* then the feature rows, parallel over rows (:662-702).  Output is byte for   */
+/* byte what lo_run_batch produces (tests/test_oracle_batches.py).             */
+/* cand: caller-allocated int32[max slots of a hop].                           */
+/* ------------------------------------------------------------------------- */
+void lo_run_batch_omp(lo_batch_ctx *c, const int32_t *all_ids, const int32_t *all_labels, int32_t total_cap,
+                      int32_t batch_size, int32_t counter, const int32_t *fanout, int32_t hops,
+                      int32_t gather, int32_t *cand)
+{
+    lo_batch_generator_kernel(c->sampled_ids, c->labels, batch_size, counter, all_ids, all_labels, total_cap,
+                              c->V, c->position_map, c->accessed_map, c->nc, c->ec, hops);
+    int32_t *nc = c->nc, *ec = c->ec;
+    for (int32_t h = 1; h <= hops; h++) {
+        const int32_t op_id = 2 * h, count = fanout[h - 1];
+        const int32_t *input_ids = (op_id == 2) ? c->sampled_ids : c->agg_src_ids + ec[2];
+        const int32_t total = nc[2] * count;
+#pragma omp parallel for schedule(static, 4096)
+        for (int32_t idx = 0; idx < total; idx++) {
+            int32_t dst = -1;
+            const int32_t src = input_ids[idx / count];
+            if (src >= 0) {
+                const int64_t start = c->indptr[src];
+                const int32_t col = (int32_t)(c->indptr[src + 1] - start);
+                if (idx % count < col) {
+                    dst = c->indices[start + (int64_t)lo_sample_index(idx, col)];
+                    if (dst < 0) dst = -1;
+                }
+            }
+            cand[idx] = dst;
+        }
+        for (int32_t idx = 0; idx < total; idx++) {
+            const int32_t dst = cand[idx];
+            if (dst < 0) continue;
+            const uint32_t bit = 1u << (dst % 32), old = c->accessed_map[dst / 32];
+            c->accessed_map[dst / 32] = old | bit;
+            if (!(old & bit)) {
+                const int32_t p = nc[0] + nc[1]++;
+                c->sampled_ids[p] = dst;
+                c->position_map[dst] = p;
+            }
+            const int32_t e = ec[0] + ec[1]++;
+            c->agg_src_ids[e] = dst;
+            c->agg_dst_ids[e] = input_ids[idx / count];
+        }
+        {
+            const int32_t e0 = ec[0], n = ec[1];
+#pragma omp parallel for schedule(static, 4096)
+            for (int32_t i = 0; i < n; i++) {
+                c->agg_src_off[e0 + i] = c->position_map[c->agg_src_ids[e0 + i]];
+                c->agg_dst_off[e0 + i] = c->position_map[c->agg_dst_ids[e0 + i]];
+            }
+        }
+        lo_update_counter(nc, ec, op_id, 0, hops);
+    }
+    if (gather && c->features && c->F > 0) {
+        const int32_t n = nc[5 + 2 * hops];
+#pragma omp parallel for schedule(static, 256)
+        for (int32_t r = 0; r < n; r++) {
+            const int32_t id = c->sampled_ids[r];
+            if (id >= 0) memcpy(c->float_features + (int64_t)r * c->F, c->features + (int64_t)(id % c->V) * c->F, (size_t)c->F * sizeof(float));
+        }
+    }
+    lo_clear_pos_map(c->position_map, c->sampled_ids, nc, hops);   /* make_update_plan, train mode */
+}

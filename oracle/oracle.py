@@ -172,8 +172,12 @@ class OracleRunner:
         self._keep.append(t)
         return C.cast(t, C.c_void_p)
 
-    def run_batch(self, all_ids, all_labels, counter, mode=0, is_presc=False, gather=True, batch_size=None):
+    def run_batch(self, all_ids, all_labels, counter, mode=0, is_presc=False, gather=True, batch_size=None, omp=False):
+        """omp=True: the OpenMP run of the same canonical schedule (lo_run_batch_omp: draws, COO offsets and row copies in
+        parallel, the order-defining compaction serial) -- resident form only; byte-identical output."""
         L = lib()
+        if omp and (is_presc or mode != 0 or self.node_map is not None or self.part_index_map is not None):
+            raise ValueError("the OpenMP oracle covers the resident train-mode batch only")
         if batch_size is not None and batch_size > self.batch_size:
             raise ValueError("batch larger than the runner was sized for (the reference sizes its buffers for raw_batch_size; "
                              "valid/test batches are up to 512, CUDA_IPC_Service.cu:101-117)")
@@ -196,6 +200,14 @@ class OracleRunner:
                      "cache_index", "sampled_ids", "float_features", "labels", "agg_src_off", "agg_dst_off", "nc",
                      "ec", "node_access_time", "edge_access_time"):
             setattr(ctx, name, getattr(self, name).ctypes.data)
+        if omp:
+            if getattr(self, "cand", None) is None:
+                self.cand = np.zeros(self.num_ids, dtype=np.int32)
+            L.lo_run_batch_omp(C.byref(ctx), _p(all_ids), _p(all_labels), C.c_int32(len(all_ids)),
+                               C.c_int32(self.batch_size if batch_size is None else batch_size), C.c_int32(counter),
+                               _p(self.fanout), C.c_int32(self.hops), C.c_int32(1 if (gather and self.with_features) else 0),
+                               _p(self.cand))
+            return self.result()
         L.lo_run_batch(C.byref(ctx), _p(all_ids), _p(all_labels), C.c_int32(len(all_ids)),
                        C.c_int32(self.batch_size if batch_size is None else batch_size), C.c_int32(counter),
                        _p(self.fanout), C.c_int32(self.hops), C.c_int32(mode), C.c_int32(1 if is_presc else 0),

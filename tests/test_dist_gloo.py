@@ -89,3 +89,107 @@ def test_two_rank_sharding_and_aggregation():
     one = S.lp_trainingset(ds, 600, 30).reshape(-1, 3, 10).transpose(0, 2, 1).reshape(-1, 3)
     got = {tuple(t) for part in lp0 for t in part}
     assert {tuple(t) for t in one.tolist()} == got
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The owner-computes exchange gather at the clique size BASELINE.json states (Kg = 8): the orchestration of
+# legion1_amd/exchange.py -- split sizes, buffer growth, order and arguments of the three all-to-alls -- run by 8 gloo ranks
+# on CPU tensors.  The four device steps (plan / local / serve / scatter: HIP kernels, parity-tested on the GPU in
+# tests/test_gpu_unified_ipc.py) are replaced by host stand-ins that follow the same contract; the GPU box allows at most 6
+# processes on its card, so this is where all eight ranks of the protocol meet.
+# ---------------------------------------------------------------------------------------------------------------------
+class _HostOps:
+    """Contract of exchange.HipOps on CPU tensors.  Shard row i of clique member j holds the F values j * 1e6 + i * 8 + c."""
+
+    def __init__(self, me, world, F, cap, rs):
+        self.me, self.world, self.F, self.cap, self.rs = me, world, F, cap, rs
+        self.shard = (me * 1e6 + np.arange(cap)[:, None] * 8 + np.arange(F)[None, :]).astype(np.float32)
+        self.feat = None
+
+    def begin(self, sampler_stream):
+        pass
+
+    def plan(self, pool, req_row, req_dst, counts):
+        n_rows = pool["rows"]
+        owner = self.rs.randint(-1, self.world, size=n_rows)        # -1: backing table, me: own shard, else a peer
+        row = self.rs.randint(0, self.cap, size=n_rows)
+        self.owner, self.row = owner, row
+        self.feat = np.full((n_rows, self.F), np.nan, np.float32)
+        k = 0
+        cnt = np.zeros(16, np.int32)
+        for j in range(self.world):                                 # owner-major request lists
+            if j == self.me:
+                continue
+            idx = np.flatnonzero(owner == j)
+            req_row[k:k + len(idx)] = torch.from_numpy(row[idx].astype(np.int32))
+            req_dst[k:k + len(idx)] = torch.from_numpy(idx.astype(np.int32))
+            cnt[j] = len(idx)
+            k += len(idx)
+        counts.copy_(torch.from_numpy(cnt))
+        local = (owner == self.me) | (owner < 0)                    # "legion_exchange_local"
+        self.feat[local] = -1.0
+
+    def counts_to_host(self, d_both, h_both):
+        h_both.copy_(d_both)
+
+    def serve(self, wanted, n, out_rows):
+        out_rows[:n] = torch.from_numpy(self.shard[wanted[:n].numpy()])
+
+    def scatter(self, pool, in_rows, req_dst, n):
+        self.feat[req_dst[:n].numpy()] = in_rows[:n].numpy()
+
+    def finish(self, sampler_stream):
+        pass
+
+    def wait(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def _exchange_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from legion1_amd.exchange import ExchangeGather
+        F, cap = 12, 5000
+        ops = _HostOps(rank, world, F, cap, np.random.RandomState(100 + rank))
+        xg = ExchangeGather(None, None, rank, world, F, "cpu", max_rows=40000, ops=ops)
+        allocs = []
+        for it, n_rows in enumerate((3000, 20000, 20000, 500, 0, 20000)):
+            info = xg.run(None, {"rows": n_rows})
+            allocs.append(xg.allocations)
+            peer = (ops.owner >= 0) & (ops.owner != rank)
+            assert info["rows_requested"] == int(peer.sum()) and info["per_owner"][rank] == 0
+            assert info["per_owner"] == [int(((ops.owner == j) & peer).sum()) for j in range(world)]
+            want = (ops.owner[:, None] * 1e6 + ops.row[:, None] * 8 + np.arange(F)[None, :]).astype(np.float32)
+            assert np.array_equal(ops.feat[peer], want[peer])               # every requested row came from the right owner and row
+            assert (ops.feat[~peer] == -1.0).all()                          # local rows were left to the local gather
+        assert allocs[2] == allocs[1] and allocs[5] == allocs[1]            # no allocation once the buffers have grown
+        assert xg.host_syncs_per_batch == 1.0 and xg.staging_syncs == 0
+        served = dist.all_gather_object
+        tot = [None] * world
+        served(tot, (info["rows_requested"], info["rows_served"]))
+        assert sum(a for a, _ in tot) == sum(b for _, b in tot)            # what is asked for is what is served, clique-wide
+        xg.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+def test_exchange_gather_protocol_with_eight_ranks():
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+    assert [o[1] for o in out] == ["ok"] * world, [o for o in out if o[1] != "ok"]

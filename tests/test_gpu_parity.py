@@ -245,6 +245,36 @@ def test_operator_plugin_api(K, oracle, small_ds):
     eng.close()
 
 
+@pytest.mark.parametrize("F,lanes", [(100, "auto"), (100, "0"), (100, "1"), (36, "1"), (7, "auto"), (52, "auto")])
+def test_padded_row_pitch_gathers_the_same_bytes(K, oracle, synth, F, lanes, monkeypatch):
+    """an HBM feature table whose rows are padded to a 128-byte-aligned pitch (legion_row_pitch; F = 100 ->
+    128 floats) and the row-aligned lane layout of k_gather must deliver exactly the dense rows -- the trainer-facing buffer stays
+    [n, F].  F = 7: scalar path with a pitch; F = 36 / 52: float4 path, C = 9 / 13 lanes per row."""
+    L = K.lib()
+    if lanes != "auto":
+        monkeypatch.setenv("LEGION_GATHER_ROW_LANES", lanes)
+    else:
+        monkeypatch.delenv("LEGION_GATHER_ROW_LANES", raising=False)
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    V = spec.V
+    rs = np.random.RandomState(F)
+    feats = rs.standard_normal((V, F)).astype(np.float32)
+    pitch = L.legion_row_pitch(F)
+    assert pitch >= F and (pitch * 4) % 128 == 0 and (pitch == F) == ((F * 4) % 128 == 0)
+    padded = np.full((V, pitch), np.float32(-777.0))       # poison in the pad floats: must never reach the output
+    padded[:, :F] = feats
+    B, fan = 300, [10, 5]
+    ref = oracle.OracleRunner(ds.indptr, ds.indices, feats, V, F, B, fan).run_batch(ds.train, ds.labels[ds.train], 1)
+    seeds = dict(train=[(ds.train, ds.labels[ds.train])])
+    eng = K.Engine(ds.indptr, ds.indices, padded.reshape(-1), V, F, seeds, B, fan, features_pitch=pitch)
+    eng.alloc_features()
+    for per_level in (True, False):
+        eng.run_batch(0, 1, per_level=per_level)
+        assert_batch_equal(ref, eng.result(0))
+    eng.close()
+
+
 def test_runner_posts_a_poisoned_pipe_when_an_operator_refuses(K, small_ds):
     """LEGION_ERR_RETURN (the tests' mode): a batch an operator refused must not leave a consumer blocked on sem_w --
     Runner_RunOnce posts the pipe with every node-counter word = -1 and keeps the error.  Here the
@@ -363,8 +393,10 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
             j = m - Ki * Kg
             rpc, nch = L.GPUCache_ShardChunkRows(eng.cache, m), L.GPUCache_ShardChunkCount(eng.cache, m)
             assert nch == (cm["node_capacity"] + rpc - 1) // rpc and (nch > 1) == (chunk_bytes is not None)
+            pitch = L.GPUCache_ShardPitch(eng.cache)       # rows of a shard start on a 128-byte line (F = 100 -> 128 floats)
+            assert pitch == L.legion_row_pitch(F) and pitch >= F and (pitch * 4) % 128 == 0
             cache_rows = np.concatenate([K.read_dev(L.GPUCache_GetShardChunk(eng.cache, m, q), np.float32,
-                                                    min(rpc, cm["node_capacity"] - q * rpc) * F).reshape(-1, F) for q in range(nch)])
+                                                    min(rpc, cm["node_capacity"] - q * rpc) * pitch).reshape(-1, pitch)[:, :F] for q in range(nch)])
             n_valid = len(range(j, min(V, cm["node_capacity"] * Kg), Kg))
             assert np.array_equal(cache_rows[:n_valid], orcs[m].caches[j][:n_valid])
             # CSR fragment, reassembled from its chunk allocations (one chunk unless chunk_bytes is small)

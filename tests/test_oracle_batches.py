@@ -176,3 +176,18 @@ def test_five_hops_vs_pyref(oracle):
     res = oracle.OracleRunner(indptr, indices, feats, V, F, 10, fan).run_batch(seeds, labels[seeds], 0)
     assert_batch_equal(pyref.run_batch(indptr, indices, feats, seeds, labels[seeds], 10, 0, fan), res)
     assert res["nc"][15] == len(res["ids"]) and res["ec"][7] == len(res["src_off"])
+
+
+def test_openmp_oracle_is_byte_identical_to_the_serial_one(oracle, synth):
+    """bench.py's "reference-semantics CPU, OpenMP" row runs lo_run_batch_omp: parallel draws / COO
+    offsets / row copies around the serial, order-defining compaction.  Same bytes as the canonical serial schedule."""
+    spec = synth.spec_for("products", scale=0.01)
+    ds = synth.generate(spec)
+    for B, fan in ((500, [25, 10]), (300, [10, 5, 3]), (1966, [4, 3])):
+        a = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+        b = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+        for it in (0, 2, 1):          # the last batch of B = 1966 is short (-1 padded): same clamp either way
+            ref = a.run_batch(ds.train, ds.labels[ds.train], it)
+            got = b.run_batch(ds.train, ds.labels[ds.train], it, omp=True)
+            for k in ("nc", "ec", "ids", "labels", "src_off", "dst_off", "features"):
+                assert np.array_equal(ref[k], got[k]), (B, fan, it, k)

@@ -52,19 +52,23 @@ def _row_sources(K, eng, g, ids, cap):
     return own, peer, slot < 0
 
 
-def test_papers100m_unified_cache_kg2_full_shape(K, synth):
-    """Config 3: 25 % of the V feature rows cached by hotness over a 2-GPU clique, 7 x 1 GiB chunks per shard."""
+@pytest.mark.parametrize("G,mode,presc", [(2, 1, 6), (8, 3, 3)])
+def test_papers100m_unified_cache_full_shape(K, synth, G, mode, presc):
+    """Config 3: 25 % of the V feature rows cached by hotness over the clique (rank-t row on GPU t % Kg, GPUCache.cu:88-108).
+    Kg = 2: 7 x 1 GiB chunks per shard.  Kg = 8 (cache_agg_mode 3, GPUCache.cu:593-607 -- the clique BASELINE.json states):
+    eight shards of 2 x 1 GiB chunks, eight-way shard tables; every owner's rows are checked byte for byte."""
     L = K.lib()
     spec, indptr, indices, feats, E = device_graph(K, synth, "papers100M")
-    B, fan, G, presc = 8000, [25, 10, 5], 2, 6
+    B, fan = 8000, [25, 10, 5]
     parts = device_seeds(K, spec, G)
     eng = _clique_engine(K, spec, indptr, indices, feats.data_ptr(), K.LOC_DEVICE, E, parts, B, fan, presc)
     cap = int(spec.V * 0.25) // G + 1
-    eng.build_cache(cache_agg_mode=1, node_capacity=cap, edge_capacity=0, train_step=presc)
-    assert L.GPUCache_Kg(eng.cache) == 2 and L.GPUCache_NodeCapacity(eng.cache, 0) == cap
-    assert L.GPUCache_ShardChunkCount(eng.cache, 0) == L.GPUCache_ShardChunkCount(eng.cache, 1) == 7      # 7.1 GB in 1 GiB chunks
+    eng.build_cache(cache_agg_mode=mode, node_capacity=cap, edge_capacity=0, train_step=presc)
+    assert L.GPUCache_Kg(eng.cache) == G and L.GPUCache_Kc(eng.cache) == 1 and L.GPUCache_NodeCapacity(eng.cache, 0) == cap
+    nch = -(-cap * spec.F * 4 // (1 << 30))                          # 7.1 GB / 1.8 GB per shard in 1 GiB chunks
+    assert all(L.GPUCache_ShardChunkCount(eng.cache, g) == nch for g in range(G)) and nch == {2: 7, 8: 2}[G]
     rs = np.random.RandomState(3)
-    for g in range(G):
+    for g in (range(G) if G == 2 else (0, 3, 7)):
         seeds_g = parts[g][0].cpu().numpy()
         for it in (0, presc + 1):           # a batch of the pre-sampling epoch and one the cache has never seen
             eng.run_batch(g, it, per_level=(it == 0))
@@ -72,14 +76,23 @@ def test_papers100m_unified_cache_kg2_full_shape(K, synth):
             check_batch(res, spec, synth, B, fan, indptr, indices, seeds_g[it * B:(it + 1) * B], rs)
             own, peer, miss = _row_sources(K, eng, g, res["ids"], cap)
             # every node of a pre-sampled batch has hotness > 0 and the cache holds more rows than were ever seen, so
-            # batch 0 is served from the two shards alone; a batch the cache has never seen also misses
+            # batch 0 is served from the shards alone; a batch the cache has never seen also misses
             kinds = (own.sum(), peer.sum(), miss.sum())
-            assert min(kinds[:2]) > 0.05 * len(res["ids"]) and (kinds[2] > 0.05 * len(res["ids"]) if it else kinds[2] == 0), kinds
+            assert own.sum() > 0.2 / G * len(res["ids"]) and peer.sum() > 0.05 * len(res["ids"]), kinds
+            assert (kinds[2] > 0.05 * len(res["ids"]) if it else kinds[2] == 0), kinds
             for name, m in (("own", own), ("peer", peer), ("miss", miss)):       # every source serves the right bytes
                 if m.sum() == 0:
                     continue
                 rows = rs.choice(np.flatnonzero(m), size=1500, replace=False)
                 assert np.array_equal(res["features"][rows], synth.features(spec, res["ids"][rows])), name
+            # per owner: the rows every clique member's shard served
+            fmap = K.read_dev(L.GPUCache_GetFeatureMap(eng.cache, g), np.int32, eng.V)
+            slot = fmap[res["ids"]]
+            for owner in range(G):
+                m = np.flatnonzero((slot >= 0) & (slot // cap == owner))
+                assert len(m) > 0.1 / G * len(slot), (g, owner, len(m))      # all eight shards serve rows
+                rows = rs.choice(m, size=min(400, len(m)), replace=False)
+                assert np.array_equal(res["features"][rows], synth.features(spec, res["ids"][rows])), ("owner", owner)
     # the cached rows are the hottest: hit rate well above the cached fraction
     assert (own.sum() + peer.sum()) / len(res["ids"]) > 0.3
     eng.close()

@@ -488,17 +488,22 @@ def test_gpu_generator_matches_numpy(K, synth):
     assert np.array_equal(tr.cpu().numpy(), ds.train)
 
 
-@pytest.mark.parametrize("workload,fan", [("products", [25, 10, 5]), ("papers100M", [25, 10, 5]), ("papers100M", [25, 10]),
-                                          ("uk-union", [25, 10, 5])])     # uk-union: E = 5.5e9 > 2^32 edge offsets, F = 256
-def test_full_size_properties(K, synth, workload, fan):
+@pytest.mark.parametrize("workload,fan,padded", [("products", [25, 10], True),      # BASELINE config 1's shape (the CPU-sampler baseline's workload)
+                                                 ("products", [25, 10, 5], True), ("products", [25, 10, 5], False),
+                                                 ("papers100M", [25, 10, 5], False), ("papers100M", [25, 10], False),
+                                                 ("uk-union", [25, 10, 5], False)])     # uk-union: E = 5.5e9 > 2^32 edge offsets, F = 256
+def test_full_size_properties(K, synth, workload, fan, padded):
     """BASELINE.json sizes (V up to 111 M, ~64 GB resident): the oracle cannot run there in seconds,
-    so check the size-independent properties every reference execution satisfies."""
+    so check the size-independent properties every reference execution satisfies.
+    padded: the HBM feature table with legion_row_pitch(F) floats per row (F = 100 -> 128), as bench.py builds it."""
     import torch
     sys_bench = __import__("bench")
     L = K.lib()
     spec = synth.spec_for(workload)
     dev = torch.device("cuda", 0)
-    indptr, indices, feats, E = sys_bench.build_graph_on_gpu(K, spec, dev)
+    pitch = L.legion_row_pitch(spec.F) if padded else 0
+    assert not padded or pitch > spec.F
+    indptr, indices, feats, E = sys_bench.build_graph_on_gpu(K, spec, dev, pitch=pitch)
     B, H = 8000, len(fan)
     tr = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
     L.legion_synth_seed_ids(None, tr.data_ptr(), 0, spec.n_train, spec.V, spec.M2, spec.C2, 1, 0)
@@ -507,7 +512,7 @@ def test_full_size_properties(K, synth, workload, fan):
     torch.cuda.synchronize()
     my_lab = lab[tr.long()].contiguous()
     seeds = dict(train=[((tr.data_ptr(), spec.n_train), (my_lab.data_ptr(), spec.n_train))])
-    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), spec.V, spec.F, seeds, B, fan, E=E)
+    eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), spec.V, spec.F, seeds, B, fan, E=E, features_pitch=pitch)
     eng.alloc_features()
     for it in (0, 7):
         eng.run_batch(0, it)

@@ -342,6 +342,15 @@ int legion_exchange_plan(void* stream, GPUCache* cache, GPUNodeStorage* noder, G
 int legion_exchange_local(void* stream, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id);
 void legion_exchange_serve(void* stream, GPUCache* cache, int32_t dev_id, const int32_t* list, int32_t n, float* out);
 void legion_exchange_scatter(void* stream, GPUMemoryPool* memorypool, const float* rows, const int32_t* req_dst, int32_t n, int32_t F);
+/* The same owner-computes gather inside ONE process that drives every GPU of the clique (the `legion` server): the requester's
+ * thread plans, reads the Kg request counts (one host synchronisation), and per owner copies the list over
+ * (hipMemcpyPeerAsync), lets the owner's GPU gather from its own shard, copies the rows back (hipMemcpyPeerAsync: the xGMI
+ * traffic as one DMA per owner) and scatters them -- all rows [0, nc[0]) of the current pipe's batch.  get_feature_kernel uses it
+ * for cached clique configurations when $LEGION_PEER_GATHER=exchange (levels < H are then deferred to the last level's op);
+ * the default is in-kernel peer loads, the reference's formulation.  stats: {batches, rows requested, host synchronisations}. */
+int legion_peer_exchange_gather(void* stream, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool, int32_t dev_id);
+void legion_peer_exchange_stats(const GPUMemoryPool* memorypool, int64_t out[3]);
+void GPUMemoryPool_ReleasePeerExchange(GPUMemoryPool* memorypool);
 
 /* ---- Operator plugin API: src/Operator.h:4-27 ------------------------------------------- */
 typedef struct OpParams {

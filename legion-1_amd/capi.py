@@ -169,6 +169,9 @@ _SIGS = {
     "legion_exchange_local": (C.c_int, [vp, vp, vp, vp, i32]),
     "legion_exchange_serve": (None, [vp, vp, i32, vp, i32, vp]),
     "legion_exchange_scatter": (None, [vp, vp, vp, vp, i32, i32]),
+    "legion_peer_exchange_gather": (C.c_int, [vp, vp, vp, vp, i32]),
+    "legion_peer_exchange_stats": (None, [vp, vp]),
+    "GPUMemoryPool_ReleasePeerExchange": (None, [vp]),
     "make_update_plan": (None, [vp, vp, vp, vp, i32, i32]),
     "update_cache": (None, [vp, vp, vp, vp, i32, i32]),
     "NewBatchGenerator": (vp, [C.c_int]), "NewRandomSampler": (vp, [C.c_int]), "NewFeatureExtractor": (vp, [C.c_int]),

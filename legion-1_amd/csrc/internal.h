@@ -200,6 +200,7 @@ void inclusive_scan_i64(hipStream_t s, const int64_t* in, int64_t* out, int32_t 
 } // namespace legion
 
 // ---- the opaque handle types (host mirrors of the reference classes) ------------------------------
+struct PeerExchange;               // peer_exchange.cpp: staging of the bulk-copy (hipMemcpyPeerAsync) gather
 struct GPUMemoryPool {
     int32_t pipeline_depth = LEGION_PIPELINE_DEPTH;
     int32_t current_pipe = 0, iter = 0, mode = 0, op_id = 0;
@@ -229,6 +230,7 @@ struct GPUMemoryPool {
     legion::HopState* hop_state = nullptr;
     int32_t* cache_search_buffer = nullptr;
     const float** row_ptr = nullptr;  // [num_ids] row source addresses of the running gather (cached configurations)
+    PeerExchange* peer_exchange = nullptr; // created by the first legion_peer_exchange_gather of this pool
     int32_t* agg_src_ids = nullptr;
     int8_t* tmp_part_ind = nullptr;
     int32_t* tmp_part_off = nullptr;

@@ -3,6 +3,7 @@
 // (src/Operator.h:4-27, Operator.cu:10-124).
 #include "internal.h"
 
+#include <cstring>
 #include <iostream>
 
 using namespace legion;
@@ -202,6 +203,18 @@ static void gather_common(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     if (g.hit_stats && (off_idx < 0 || off_idx == 3 + 2 * p->hops)) GPUCache_HitSamplingDone(cache, dev_id, strm_hdl);
 }
 
+// $LEGION_PEER_GATHER=exchange and a filled clique cache (Kg > 1, every member in this process): the peers' rows travel as bulk
+// copies (peer_exchange.cpp) instead of in-kernel xGMI loads
+static bool use_peer_exchange(const GPUCache* cache, const GPUMemoryPool* p, int32_t dev_id)
+{
+    const char* e = getenv("LEGION_PEER_GATHER");
+    if (!e || strcmp(e, "exchange") != 0 || !cache || p->capturing) return false;
+    if (cache->Kg <= 1 || dev_id < 0 || dev_id >= cache->device_count || !cache->ctl[dev_id]->feat_map || cache->ctl[dev_id]->node_capacity <= 0) return false;
+    const int K0 = (dev_id / cache->Kg) * cache->Kg;
+    for (int j = 0; j < cache->Kg; j++) if (is_remote_device(K0 + j)) return false;
+    return true;
+}
+
 // get_feature_kernel, Kernels.cu:706-748.  op_id 2l+1 gathers level l.
 void get_feature_kernel(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* memorypool,
                         int32_t dev_id, int32_t op_id, int in_memory)
@@ -210,6 +223,10 @@ void get_feature_kernel(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder, 
     const int l = (op_id - 1) / 2;
     if (op_id < 1 || !(op_id & 1) || l > memorypool->hops) { LEGION_ARG_ERROR("get_feature_kernel: op_id must be 1,3,..,2*hops+1"); return; }
     if (!in_memory) return; // the reference only launches the in-memory path (Kernels.cu:737-746)
+    if (use_peer_exchange(cache, memorypool, dev_id)) {   // one exchange per batch: the last level's op gathers every level
+        if (l == memorypool->hops) legion_peer_exchange_gather(strm_hdl, cache, noder, memorypool, dev_id);
+        return;
+    }
     gather_common(strm_hdl, cache, noder, memorypool, dev_id, 3 + 2 * l, 4 + 2 * l, memorypool->level_bound[l]);
 }
 
@@ -218,6 +235,7 @@ void get_feature_kernel_all(void* strm_hdl, GPUCache* cache, GPUNodeStorage* nod
 {
     if (!noder || !pool_ready(memorypool, "get_feature_kernel_all")) return;
     if (!in_memory) return;
+    if (use_peer_exchange(cache, memorypool, dev_id)) { legion_peer_exchange_gather(strm_hdl, cache, noder, memorypool, dev_id); return; }
     gather_common(strm_hdl, cache, noder, memorypool, dev_id, -1, 0, memorypool->num_ids); // rows [0, nc[0])
 }
 

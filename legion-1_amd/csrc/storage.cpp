@@ -551,6 +551,7 @@ void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial) { p->batch_
 void GPUMemoryPool_Finalize(GPUMemoryPool* p)
 {
     if (!p || !p->owns_scratch) return;
+    GPUMemoryPool_ReleasePeerExchange(p);
     (void)hipFree(p->pos_map); (void)hipFree(p->cand); for (auto& a : p->aux2) { (void)hipFree(a); a = nullptr; } (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
     (void)hipFree(p->hop_state); (void)hipFree(p->cache_search_buffer); (void)hipFree((void*)p->row_ptr); p->row_ptr = nullptr; (void)hipFree(p->agg_src_ids);
     (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off); (void)hipFree(p->ctl); p->ctl = nullptr; if (p->rows_seen) { (void)hipHostFree(p->rows_seen); p->rows_seen = nullptr; p->rows_seen_dev = nullptr; }

@@ -52,7 +52,7 @@ def _row_sources(K, eng, g, ids, cap):
     return own, peer, slot < 0
 
 
-@pytest.mark.parametrize("G,mode,presc", [(2, 1, 6), (8, 3, 3)])
+@pytest.mark.parametrize("G,mode,presc", [(2, 1, 6), (8, 3, 1)])     # G x presc pre-sampled batches must fit the cache (see below)
 def test_papers100m_unified_cache_full_shape(K, synth, G, mode, presc):
     """Config 3: 25 % of the V feature rows cached by hotness over the clique (rank-t row on GPU t % Kg, GPUCache.cu:88-108).
     Kg = 2: 7 x 1 GiB chunks per shard.  Kg = 8 (cache_agg_mode 3, GPUCache.cu:593-607 -- the clique BASELINE.json states):

@@ -443,7 +443,31 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
                     assert (n_hit.value, n_rows.value) == (int(hit.sum()), len(hit)) and abs(rate - hit.mean()) < 1e-12
                 # hits and misses both occur, unless the clique-wide cache (capacity x Kg) already holds nearly every node
                 assert 0 < hit.sum() and (hit.sum() < len(hit) or L.GPUCache_NodeCapacity(eng.cache, g) * Kg > 0.9 * V)
+    # the bulk-copy peer path of the one-process server (peer_exchange.cpp, $LEGION_PEER_GATHER=exchange): the peers' rows arrive
+    # through hipMemcpyPeerAsync instead of in-kernel loads -- same bytes, one host synchronisation per batch
+    if Kg > 1 and all(L.GPUCache_NodeCapacity(eng.cache, g) > 0 for g in range(G)):
+        monkeypatch.setenv("LEGION_PEER_GATHER", "exchange")
+        for g in range(G):
+            for it, per_level in ((0, True), (1, False)):
+                ref = orcs[g].run_batch(parts[g], ds.labels[parts[g]], it)
+                feat = eng.out[g][0]["feat"]
+                L.SetGPUDevice(g)
+                L.d_memset_async(feat.ptr, 0xFF, feat.nbytes, None)       # poison: every row must be rewritten
+                L.d_stream_sync(None)
+                eng.run_batch(g, it, per_level=per_level)
+                assert_batch_equal(ref, eng.result(g))
+            st = (C.c_int64 * 3)()
+            L.legion_peer_exchange_stats(eng.pools[g], st)
+            slot = orcs[g].node_map[eng.result(g)["ids"]]
+            K0 = (g // Kg) * Kg
+            assert st[0] == 2 and st[2] == 2 and st[1] > 0, list(st)       # 2 batches, 2 host syncs, peers were asked for rows
+            assert int(((slot >= 0) & (slot // cm_cap(eng, L, g) != g - K0)).sum()) > 0
+        monkeypatch.delenv("LEGION_PEER_GATHER")
     eng.close()
+
+
+def cm_cap(eng, L, g):
+    return max(1, L.GPUCache_NodeCapacity(eng.cache, g))
 
 
 def test_cost_model_everything_fits(K, small_ds):

@@ -1111,16 +1111,16 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // cache chunks are hipMalloc'ed (256-byte aligned) and hold whole rows: F % 4 == 0 keeps rows 16-byte aligned
     bool vec4 = (g.F % 4 == 0) && (((uintptr_t)g.table | (uintptr_t)g.dst) % 16 == 0);
     const int C = vec4 ? g.F / 4 : g.F;
-    // row-aligned lane layout (see k_gather): only when a wave would otherwise straddle rows at odd offsets
+    // row-aligned lane layout (see k_gather): measured at F = 100 (profiles/r03_other_shapes.md) it is SLOWER than the dense
+    // q / C layout (146.8 vs 137.2 us at the products {25,10} shape: the idle lanes cost more issue slots than the aligned
+    // starts save), so it is only used on request ($LEGION_GATHER_ROW_LANES=1)
     const char* lpr_env = getenv("LEGION_GATHER_ROW_LANES");
-    const int lpr_mode = lpr_env ? atoi(lpr_env) : -1;   // -1 auto, 0 never, 1 always
     a.lpr_shift = -1;
     int lanes = C;
-    if (vec4 && C < 64 && (64 % C) != 0 && lpr_mode != 0) {
+    if (vec4 && C < 64 && (64 % C) != 0 && lpr_env && atoi(lpr_env) == 1) {
         int sh = 0;
         while ((1 << sh) < C) sh++;
-        // idle lanes cost issue slots, not bandwidth: worth it when at most ~1/4 of the lanes idle, or when forced
-        if (lpr_mode == 1 || (C * 4 >= (1 << sh) * 3)) { a.lpr_shift = sh; lanes = 1 << sh; }
+        a.lpr_shift = sh; lanes = 1 << sh;
     }
     if ((int64_t)rows_bound * lanes >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);

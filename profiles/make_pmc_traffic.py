@@ -2,6 +2,8 @@
 """Collect HBM traffic per kernel with rocprofv3 PMC counters and write profiles/<tag>_pmc_hbm_traffic.json.
 
 Run on the GPU box from the repository root:   python3 profiles/make_pmc_traffic.py r01
+Another shape:   python3 profiles/make_pmc_traffic.py r03 products_2hop --workload products --fanout 25,10
+(writes profiles/r03_pmc_hbm_traffic_products_2hop.json; bench.py only reads the un-suffixed file of the default workload)
 One rocprofv3 pass per counter (FETCH_SIZE, WRITE_SIZE), no trace domains, the program itself after `--`.
 Units / corrections as prescribed in MI355X_MICROARCH.md (HBM section): rocprofv3 reports both counters in KiB;
 on gfx950 FETCH_SIZE counts half of the bytes of wide (16 B/lane) coalesced reads -> x2 for k_gather; the scattered
@@ -16,7 +18,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-out_dir = os.path.join(ROOT, "gpurun_out", "pmc_traffic")
+suffix = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ""
+extra = sys.argv[(3 if suffix else 2):]
+out_dir = os.path.join(ROOT, "gpurun_out", "pmc_traffic" + ("_" + suffix if suffix else ""))
 os.makedirs(out_dir, exist_ok=True)
 env = dict(os.environ, TMPDIR="/tmp")
 per = collections.defaultdict(dict)
@@ -24,7 +28,7 @@ bench = None
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, counter)
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-           "--steps", "10", "--warmup", "2", "--min-time", "0", "--headline-only", "--cpu-baseline-seconds", "0"]
+           "--steps", "10", "--warmup", "2", "--min-time", "0", "--headline-only", "--cpu-baseline-seconds", "0"] + extra
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         sys.exit(r.stdout[-2000:] + r.stderr[-2000:])
@@ -46,7 +50,8 @@ alg = bench["gather_algorithmic_bytes_per_batch"]
 samp = sum((v.get("FETCH_SIZE_KiB_avg", 0) + v.get("WRITE_SIZE_KiB_avg", 0)) * 1024 * v["launches"] for k, v in per.items()
            if not k.startswith("k_gather")) / batches
 doc = {
-    "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --min-time 0 --headline-only --cpu-baseline-seconds 0  (one pass per counter: FETCH_SIZE, WRITE_SIZE; profiles/make_pmc_traffic.py)",
+    "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 10 --warmup 2 --min-time 0 --headline-only --cpu-baseline-seconds 0 "
+               + " ".join(extra) + " (one pass per counter: FETCH_SIZE, WRITE_SIZE; profiles/make_pmc_traffic.py)",
     "workload": bench["config"]["workload"],
     "units": "rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; gfx950 correction: FETCH_SIZE x2 for the 16 B/lane reads of k_gather; sampler kernels raw",
     "kernels": per,
@@ -56,6 +61,6 @@ doc = {
                 "raw_over_algorithmic": round(samp / bench["sampler_algorithmic_bytes_per_batch"], 3),
                 "note": "20 N + 28 E + 8 U per hop counts 4/8-byte elements; every scattered element moves a 32/64-byte sector"},
 }
-path = os.path.join(ROOT, "profiles", tag + "_pmc_hbm_traffic.json")
+path = os.path.join(ROOT, "profiles", tag + "_pmc_hbm_traffic" + ("_" + suffix if suffix else "") + ".json")
 json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps(doc["k_gather"]), json.dumps(doc["sampler"]))

@@ -1050,9 +1050,9 @@ def run_cpu_baseline(args, spec, indptr, indices, feats, mine, my_labels, B, fan
                       + ("" if with_feat else ", sampler+COO only (no feature gather)"),
             "seconds": round(t_used, 2), "host_copy_s": round(copy_s, 1), "cpu_model": cpu_model,
             "host_cores_available": os.cpu_count(), "host_cores_in_affinity_mask": affinity,
-            "threads_note": "OpenMP legs use omp_get_max_threads(), which follows the affinity mask / cgroup quota of this process: "
-                            "on the GPU pool a one-GPU lease is pinned to a share of the host's hardware threads, so "
-                            "`cores` can be below host_cores_available"}
+            "threads_note": "the OpenMP legs run with omp_get_max_threads() threads.  bench.py imports torch first, and torch sizes the shared "
+                            "OpenMP pool to the PHYSICAL core count (SMT siblings unused): e.g. 128 threads on a 2 x 64-core host with 256 "
+                            "hardware threads.  `cores` is what was really used."}
 
 
 def run_dgl_baseline(dgl, torch, indptr, indices, feats, ids, B, fan, budget):

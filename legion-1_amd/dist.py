@@ -28,15 +28,21 @@ def train_steps(n_seeds_per_rank, batch_size: int) -> int:
     return (min(n_seeds_per_rank) - 1) // batch_size
 
 
+def _active(world: int) -> bool:
+    """Collectives run when there is more than one rank -- or when $LEGION_DIST_FORCE=1 asks for them on an initialised
+    1-rank group (tests/test_gpu_nccl_single.py: the RCCL code paths of these helpers on a one-GPU box)."""
+    return world > 1 or os.environ.get("LEGION_DIST_FORCE") == "1"
+
+
 def barrier(world: int):
-    if world > 1:
+    if _active(world):
         import torch.distributed as dist
         dist.barrier()
 
 
 def aggregate(elapsed_s: float, totals, world: int, device=None):
     """(max over ranks of elapsed, element-wise sum over ranks of totals)."""
-    if world <= 1:
+    if not _active(world):
         return float(elapsed_s), [float(t) for t in totals]
     import torch
     import torch.distributed as dist
@@ -51,7 +57,7 @@ def aggregate(elapsed_s: float, totals, world: int, device=None):
 
 def aggregate_max_vec(values, world: int, device=None):
     """Element-wise MAX over ranks of a list of floats (per-window elapsed times: every rank runs the same windows)."""
-    if world <= 1:
+    if not _active(world):
         return [float(v) for v in values]
     import torch
     import torch.distributed as dist
@@ -71,7 +77,7 @@ def allreduce_device_u64(capi, ptr: int, n: int, world: int, device=None):
     """In-place SUM over ranks of a u64[n] device array owned by the C library (the clique-wide hotness
     sum of CandidateSelection, GPUCache.cu:624-627, as a collective instead of peer reads).
     RCCL when the process group is nccl; with gloo (CPU tests) the array is staged through the host."""
-    if world <= 1:
+    if not _active(world):
         return
     import numpy as np
     import torch
@@ -93,7 +99,7 @@ def allreduce_device_u64(capi, ptr: int, n: int, world: int, device=None):
 
 
 def allgather_object(obj, world: int):
-    if world <= 1:
+    if not _active(world):
         return [obj]
     import torch.distributed as dist
     out = [None] * world

@@ -157,7 +157,8 @@ def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0
             print("bench.py: the headline line was printed, but a later leg did not finish in time (see \"legs_failed\" in the line)",
                   file=sys.stderr)
             return LEG_HUNG_EXIT
-        return next((c for c in codes if c and c > 0), 1)      # a rank's own exit code; 1 if only stragglers were stopped
+        # a rank's own exit code (one that died for its own reasons first); 1 if only stragglers were stopped
+        return next((c for c in codes if c and c > 0 and c != LEG_HUNG_EXIT), next((c for c in codes if c and c > 0), 1))
     return 0
 
 
@@ -388,6 +389,8 @@ def extra_leg(c, name):
     # HBM replica (a pinned-host backing table of 137 GB per process is not attempted here; tests/test_gpu_full_shape.py covers it)
     a.workload, a.fanout, a.task, a.topo_frac, a.cache_frac, a.no_exchange_leg = "uk-union", "25,10", "node", 0.3, 0.10, True
     c2.fan, c2.H = [25, 10], 2
+    for k in ("indptr", "indices", "feats", "mine", "my_labels"):     # drop the headline graph FIRST: c2 is a shallow copy, and
+        setattr(c, k, None)                                          # 64 GB + 160 GB would otherwise be resident together
     load_workload(c2, "uk-union")
     for k in ("spec", "pitch", "indptr", "indices", "feats", "E", "feat_ptr", "feat_loc", "host_table", "mine", "my_labels", "n_mine", "steps_avail", "gen_s"):
         setattr(c, k, getattr(c2, k))      # the headline graph is gone: later legs see this one

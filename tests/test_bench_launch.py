@@ -93,3 +93,57 @@ def test_gpus_2_without_gpus_is_an_error_not_a_silent_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and r.stdout == ""
+
+
+# ---- legs after the headline: LegGuard (a hung leg must not look like success, and no rank may be left in a collective) ----
+class _Ctx:
+    rank, world = 0, 1
+
+    def __init__(self):
+        import legion1_amd.dist as D
+        self.D = D
+
+
+def test_a_leg_that_raises_is_reported_and_the_run_goes_on():
+    line = {"legs_failed": [], "extra_legs": {}}
+    g = bench.LegGuard(_Ctx(), line)
+
+    def boom():
+        raise RuntimeError("shard import failed")
+    res = g.run("uk_union", 5.0, boom)
+    assert "shard import failed" in res["error"]
+    assert line["legs_failed"] == [{"leg": "uk_union", "error": "rank 0: " + res["error"], "hung": False}]
+    assert g.run("lp", 5.0, lambda: {"value": 1.0}) == {"value": 1.0} and len(line["legs_failed"]) == 1
+
+
+def test_a_leg_that_hangs_prints_the_headline_names_the_leg_and_exits_3():
+    code = ("import sys, json, time; sys.path.insert(0, %r)\n"
+            "import bench, legion1_amd.dist as D\n"
+            "class _Ctx:\n"
+            "    rank, world, D = 0, 1, D\n"
+            "line = {'metric': 'm', 'value': 42.0, 'legs_failed': [], 'extra_legs': {}}\n"
+            "g = bench.LegGuard(_Ctx(), line)\n"
+            "def stuck():\n"
+            "    g.partial = {'value': 7.0}\n"
+            "    time.sleep(60)\n"
+            "g.run('unified_cache', 0.5, stuck)\n"
+            "print('never')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, cwd=ROOT)
+    assert r.returncode == bench.LEG_HUNG_EXIT == 3 and "never" not in r.stdout
+    import json
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] == 42.0                                          # the headline survives
+    assert line["legs_failed"][0]["leg"] == "unified_cache" and line["legs_failed"][0]["hung"] is True
+    assert "time.sleep" in line["legs_failed"][0]["stuck_at"] or "stuck" in line["legs_failed"][0]["stuck_at"]
+    assert line["unified_cache"] == {"value": 7.0, "error": "did not finish within 0 s"} or line["unified_cache"]["value"] == 7.0
+    assert "Thread" in r.stderr or "File" in r.stderr                     # faulthandler dump of every thread
+
+
+def test_parent_passes_the_hung_leg_exit_code_on():
+    procs = [FakeProc([True], bench.LEG_HUNG_EXIT) for _ in range(4)]
+    rc, _ = _launch(procs)
+    assert rc == bench.LEG_HUNG_EXIT
+    # a rank that died for another reason still wins over the "leg hung" code
+    procs = [FakeProc([True], bench.LEG_HUNG_EXIT), FakeProc([True], 1)]
+    rc, _ = _launch(procs, grace_s=0.0)
+    assert rc == 1

@@ -43,7 +43,7 @@ constexpr uint32_t kProvisional = 0x80000000u; // | slot idx : claimed in the ru
 #endif
 constexpr int kTile = LEGION_KTILE;            // sampler slots per workgroup tile
 constexpr int kBlock = 256;                    // threads per workgroup
-static_assert(kTile >= kBlock && kTile <= 4096 && (kTile & (kTile - 1)) == 0, "LEGION_KTILE: a power of two in [256, 4096]");
+static_assert(kTile >= kBlock && kTile <= 2048 && (kTile & (kTile - 1)) == 0, "LEGION_KTILE: a power of two in [256, 2048] (k_sample stages 16 bytes of row descriptor per slot in static LDS)");
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 // k_write packs the (edges, nodes) counted in front of a tile group INSIDE its prefix block into 16 bits each: a block of
 // 2^lpb groups of 2^gshift tiles may hold at most 65536 / kTile tiles, i.e. lpb + gshift <= kPrefixBits (6 at kTile = 1024)

@@ -146,7 +146,8 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
 }
 
 // Arguments of a gather over the rows (nc[off_idx], nc[size_idx]) of the current pipe; false (sticky error) if it cannot run.
-static bool gather_args(GatherArgs& g, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* p, int32_t dev_id, int off_idx, int size_idx)
+static bool gather_args(GatherArgs& g, GPUCache* cache, GPUNodeStorage* noder, GPUMemoryPool* p, int32_t dev_id, int off_idx, int size_idx,
+                        bool count_hits = true)
 {
     const int32_t F = noder->float_attr_len;
     if (F < 0) std::cout << "error feature len\n"; // Kernels.cu:719-721
@@ -187,7 +188,7 @@ static bool gather_args(GatherArgs& g, GPUCache* cache, GPUNodeStorage* noder, G
         g.row_ptr = p->row_ptr; // FindFeat + source selection as their own pass over the rows (k_row_ptrs)
         // the last gather of a batch: level `hops` of the per-level gathers, or the one gather over all rows
         // (a recorded batch graph would bake the decision in: graphs never sample)
-        if (!p->capturing) g.hit_stats = GPUCache_HitSampling(cache, dev_id, off_idx < 0 || off_idx == 3 + 2 * p->hops, off_idx < 0 || off_idx == 3);
+        if (!p->capturing && count_hits) g.hit_stats = GPUCache_HitSampling(cache, dev_id, off_idx < 0 || off_idx == 3 + 2 * p->hops, off_idx < 0 || off_idx == 3);
     }
     if (!g.table && !g.feat_map) { LEGION_ARG_ERROR("get_feature_kernel: no feature table"); return false; }
     return true;
@@ -250,7 +251,7 @@ int legion_exchange_plan(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder,
     if (!noder || !cache || !req_row || !req_dst || !counts || !pool_ready(memorypool, "legion_exchange_plan")) return -1;
     GPUMemoryPool* p = memorypool;
     GatherArgs g;
-    if (!gather_args(g, cache, noder, p, dev_id, -1, 0)) return -1;
+    if (!gather_args(g, cache, noder, p, dev_id, -1, 0, false)) return -1;      // the hit counter belongs to the lookup pass of k_row_ptrs
     if (!g.feat_map || !g.row_ptr || !p->cache_search_buffer) { LEGION_ARG_ERROR("legion_exchange_plan: needs a filled unified cache"); return -1; }
     launch_exchange_plan((hipStream_t)strm_hdl, g, dev_id % cache->Kg, cache->Kg, p->cache_search_buffer, counts, req_row, req_dst, p->num_ids);
     return error_pending() ? -1 : 0;
@@ -262,10 +263,9 @@ int legion_exchange_local(void* strm_hdl, GPUCache* cache, GPUNodeStorage* noder
     if (!noder || !cache || !pool_ready(memorypool, "legion_exchange_local")) return -1;
     GPUMemoryPool* p = memorypool;
     GatherArgs g;
-    if (!gather_args(g, cache, noder, p, dev_id, -1, 0)) return -1;
+    if (!gather_args(g, cache, noder, p, dev_id, -1, 0, false)) return -1;
     if (!g.row_ptr) { LEGION_ARG_ERROR("legion_exchange_local: needs a filled unified cache"); return -1; }
     g.row_ptr_ready = true;   // k_exch_fill resolved the local rows (and left the peers' rows without a source)
-    g.hit_stats = nullptr;
     launch_gather((hipStream_t)strm_hdl, g, p->num_ids);
     return error_pending() ? -1 : 0;
 }

@@ -89,6 +89,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-baseline-seconds", type=float, default=10.0,
                     help="CPU time budget of the baseline legs together (60 %% reference-semantics oracle, 40 %% DGL-semantics sampler); 0 disables")
     ap.add_argument("--no-cpu-features", action="store_true", help="CPU baseline: sampler only (skip the 57 GB host copy)")
+    ap.add_argument("--measure-traffic", default="auto", choices=["auto", "off"],
+                    help="auto (N = 1, tables in HBM, rocprofv3 on PATH, not already under a profiler): after the timed legs, two short child "
+                         "runs of this workload under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` measure the HBM bytes of the dominant kernel for "
+                         "roofline.traffic; off: quote the newest committed profiles/r*_pmc_hbm_traffic.json instead")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the parent gives up on its ranks")
     return ap.parse_args(argv)
 
@@ -251,6 +255,11 @@ def worker(args):
     # measured streaming-copy rate of this box (float4 copy kernel sized like the gather, read + write bytes)
     if rank == 0 and line.get("roofline") is not None:
         line["roofline"]["measured_copy_GBps"] = measure_copy(c)
+        if (world == 1 and args.measure_traffic == "auto" and not args.headline_only and args.table == "device" and args.cache == "replicated"
+                and args.gather == "all" and args.pipeline == "serial"):
+            got = measure_traffic_in_run(args)
+            if got is not None:
+                line["roofline"].update(got)
     if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
         feats = c.feats
         if c.host_table is not None:   # the table already is host memory: view it, no copy
@@ -960,6 +969,51 @@ def unified_cache_traffic(c, eng, me, cache_info, gather_ms):
                     "xgmi_peak_GBps_per_gpu": XGMI_PEAK_GBPS, "xgmi_frac_of_peak": round(s_rate / world / XGMI_PEAK_GBPS, 4),
                     "xgmi_note": "peer rows x 4F bytes / the gather's HIP-event time (the gather also reads own-shard and replica rows in that time)"})
     return out
+
+
+def measure_traffic_in_run(args):
+    """HBM bytes per launch of the dominant kernel (k_gather), from the PMC counters, as MI355X_MICROARCH.md prescribes: one
+    `rocprofv3 --pmc` pass per counter (FETCH_SIZE, WRITE_SIZE; no trace domains), the program itself after `--`; both counters
+    come in KiB, and on gfx950 FETCH_SIZE counts half of the bytes of 16 B/lane reads (x2).  Counters cannot be read from inside
+    a process, so each pass is a short child run of this same workload (10 steps); the parent's graph stays resident meanwhile.
+    Returns the roofline fields to overwrite, or None (not on PATH, already under a profiler, a pass failed: the committed file stays)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3")
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("LEGION_BENCH_PMC_CHILD")
+    if not rocprof or under_profiler:
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "2", "--min-time", "0", "--headline-only",
+             "--cpu-baseline-seconds", "0", "--measure-traffic", "off", "--workload", args.workload, "--fanout", args.fanout,
+             "--batch", str(args.batch), "--scale", str(args.scale), "--task", args.task, "--skew", str(args.skew), "--row-pitch", args.row_pitch]
+    env = dict(os.environ, TMPDIR="/tmp", LEGION_BENCH_PMC_CHILD="1")
+    kib, launches, t0 = {}, 0, time.time()
+    tmp = tempfile.mkdtemp(prefix="legion_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if "legion::k_gather" in row["Kernel_Name"] and row["Counter_Name"] == counter]
+            if not vals:
+                return None
+            kib[counter], launches = sum(vals) / len(vals), len(vals)
+    except Exception:   # noqa: BLE001 -- evidence only: never lose the line over it
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    read, write = kib["FETCH_SIZE"] * 1024 * 2, kib["WRITE_SIZE"] * 1024
+    return {"traffic": int(read + write), "traffic_measured_in_run": True,
+            "traffic_source": "two child runs of this workload started by this run, after its timed legs: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                              "(one pass per counter, no trace domains; KiB; FETCH_SIZE x2 for the 16 B/lane reads on gfx950); average of %d k_gather "
+                              "launches (batches 0-11 of the same seed list; the timed windows run batches %d-%d)" % (launches, args.warmup, args.warmup + args.steps - 1),
+            "traffic_hbm_read_bytes": int(read), "traffic_hbm_write_bytes": int(write), "traffic_passes_s": round(time.time() - t0, 1)}
 
 
 def measure_copy(c):

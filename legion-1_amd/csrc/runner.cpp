@@ -535,7 +535,12 @@ void Server_Run(Server* s)
 // Finalize, Server.cu:137-146
 void Server_Finalize(Server* s)
 {
-    for (int i = 0; i < s->shard_count; i++) Runner_Finalize(s->runners[i], s->params[i]);
+    for (int i = 0; i < s->shard_count; i++) {
+        int64_t st[3];
+        legion_peer_exchange_stats(Runner_GetMemoryPool(s->runners[i]), st);     // $LEGION_PEER_GATHER=exchange: what the bulk-copy gather did
+        if (st[0] > 0) std::cout << i << " peer exchange gather: " << st[0] << " batches, " << st[1] << " rows over hipMemcpyPeerAsync, " << st[2] << " host syncs\n";
+        Runner_Finalize(s->runners[i], s->params[i]);
+    }
     GPUGraphStorage_Finalize(s->graph);
     GPUNodeStorage_Finalize(s->noder);
     IPCEnv_Finalize(s->env);

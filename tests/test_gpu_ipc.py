@@ -87,10 +87,13 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
     assert ("Tables stay in pinned host memory" if tables == "host" else "Tables replicated into HBM") in text
 
 
-def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
+@pytest.mark.parametrize("peer_gather", ["in-kernel", "exchange"])
+def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle, peer_gather):
     """`legion 2 1`: two logical GPUs in ONE server process (a thread per GPU, Server.cu:119-127), Kg = 2 unified
     cache with in-kernel peer reads (both logical GPUs map onto the box's single device), one trainer process
-    per GPU.  Each trainer must see exactly its partition's batches (tid % 2 split, GPUGraphStore.cu:332-346)."""
+    per GPU.  Each trainer must see exactly its partition's batches (tid % 2 split, GPUGraphStore.cu:332-346).
+    peer_gather = exchange: the same server with $LEGION_PEER_GATHER=exchange -- the peers' rows arrive as hipMemcpyPeerAsync
+    bulk copies (peer_exchange.cpp), driven concurrently by the two runner threads, each launching on the other's device."""
     spec = synth.spec_for("products", scale=0.004)
     ds = synth.generate(spec)
     data = str(tmp_path / "ds") + "/"
@@ -100,9 +103,11 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
         f.write(synth.meta_config_line(ds, data, B, budget, epochs, 0))
-    ns = "g2_%d_" % os.getpid()
+    ns = "g2_%d_%s_" % (os.getpid(), peer_gather[:2])
     # host tables: with HBM replicas the server would (rightly) not build a cache at all
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_TABLES="host")
+    if peer_gather == "exchange":
+        env["LEGION_PEER_GATHER"] = "exchange"
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:
         server = subprocess.Popen([SERVER, str(G), "1", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,
@@ -129,6 +134,7 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle):
     steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)
     text = open(log).read()
     assert "xGMI Clique: 1 GPU Per Clique: 2" in text and "Feat capacity" in text   # the cost model sized a real cache
+    assert ("peer exchange gather:" in text) == (peer_gather == "exchange"), text[-1500:]
     H = len(fan)
     for g in range(G):
         got = json.load(open(clients[g][0]))

@@ -139,6 +139,13 @@ void GPUGraphStorage_Finalize(GPUGraphStorage* g);
 /* MI355X-first: copy the whole CSR into the HBM of every local GPU (one replica per physical device); the
  * sampler then reads its own replica instead of the pinned-host table.  Returns bytes per replica (0: nothing done). */
 int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g);
+/* Head tables over the HBM copies of the whole CSR (built by Build() for a device-resident CSR and by ReplicateToDevices()):
+ * one 64- or 128-byte entry per node holding its degree and -- when they fit -- its neighbours, so that the sampler reads ONE
+ * random line per low-degree source row instead of the indptr pair and the adjacency line (MI355X: HBM capacity traded for
+ * random accesses; papers100M shape: 7.1 GB).  $LEGION_HEAD_TABLE = auto | 0 | 16 | 32 (ints per entry).  Same draws, same
+ * neighbours: bit-identical output.  Returns the bytes per device (0: none built). */
+int64_t GPUGraphStorage_BuildHeadTables(GPUGraphStorage* g);
+int32_t* GPUGraphStorage_GetHeadTable(const GPUGraphStorage* g, int32_t dev_id, int32_t* ints_per_entry);
 int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g);
 int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g);
 int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g);

@@ -220,11 +220,19 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                         start = ip[0];
                         rowp = ix + start;
                     }
+                    deg = (int32_t)(ip[1] - start); // int32 truncation as in Kernels.cu:393,396
+                } else if (!PRESC && a.csr.head) {
+                    // head table: degree and -- for rows that fit -- the neighbours themselves in ONE line
+                    const int32_t* hp = a.csr.head + ((int64_t)src << a.csr.head_shift);
+                    const int4 h4 = *reinterpret_cast<const int4*>(hp);        // entries are 64 / 128-byte aligned: one 16-byte load
+                    deg = h4.x;
+                    if (deg < (1 << a.csr.head_shift)) rowp = hp + 1;
+                    else rowp = ix + (int64_t)(((uint64_t)(uint32_t)h4.z << 32) | (uint32_t)h4.y);
                 } else {
                     start = ip[0];
                     rowp = ix + start;
+                    deg = (int32_t)(ip[1] - start);
                 }
-                deg = (int32_t)(ip[1] - start); // int32 truncation as in Kernels.cu:393,396
             }
             s_row[r] = rowp;
             s_deg[r] = deg;
@@ -952,6 +960,24 @@ __global__ void k_chunk_ends(const int64_t* frag_indptr, int32_t capacity, int32
     }
     ends[q] = frag_indptr[lo];
 }
+// Head table over a device-resident CSR (see CsrTables::head): W = 2^shift ints per node, one lane per int
+__global__ void k_build_head(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int32_t V, int32_t shift,
+                             int32_t* __restrict__ head)
+{
+    const int64_t n = (int64_t)V << shift;
+    const int32_t W = 1 << shift;
+    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = (int32_t)(i >> shift), c = (int32_t)(i & (W - 1));
+        const int64_t start = indptr[v];
+        const int32_t deg = (int32_t)(indptr[v + 1] - start);      // the sampler's int32 degree (Kernels.cu:393,396)
+        int32_t out = 0;
+        if (c == 0) out = deg;
+        else if (deg >= 0 && deg < W) out = (c <= deg) ? indices[start + c - 1] : 0;
+        else if (c == 1) out = (int32_t)(uint32_t)(start & 0xFFFFFFFFll);
+        else if (c == 2) out = (int32_t)(uint32_t)((uint64_t)start >> 32);
+        head[i] = out;
+    }
+}
 // GetEdgeMem (GPUCache.cu:35-41)
 __global__ void k_edge_mem(const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)
 {
@@ -1271,6 +1297,12 @@ void launch_chunk_ends(hipStream_t s, const int64_t* frag_indptr, int32_t capaci
 {
     if (nch <= 1) return;
     k_chunk_ends<<<(nch + 63) / 64, 64, 0, s>>>(frag_indptr, capacity, edge_shift, nch, ends);
+    HIP_CHECK_LAST();
+}
+void launch_build_head(hipStream_t s, const int64_t* indptr, const int32_t* indices, int32_t V, int32_t head_shift, int32_t* head)
+{
+    if (V <= 0) return;
+    k_build_head<<<grid_for((int64_t)V << head_shift, 256, 64), 256, 0, s>>>(indptr, indices, V, head_shift, head);
     HIP_CHECK_LAST();
 }
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)

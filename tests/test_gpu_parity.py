@@ -245,6 +245,49 @@ def test_operator_plugin_api(K, oracle, small_ds):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", ["0", "16", "32", "auto"])
+def test_head_table_layout_and_parity(K, oracle, synth, mode, monkeypatch):
+    """Round 3: the sampler reads a node's degree and -- when they fit -- its neighbours from ONE 64/128-byte head entry instead of
+    the indptr pair + the adjacency line (GPUGraphStorage_BuildHeadTables).  Layout vs numpy, and the batches are bit-identical to the
+    oracle with the table off, 16 ints, 32 ints and auto (degree-0 rows, rows that fit exactly, rows one too long, -1 neighbours)."""
+    L = K.lib()
+    monkeypatch.setenv("LEGION_HEAD_TABLE", mode)
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    V = spec.V
+    # reshape the degree sequence so that every boundary case occurs: 0, 1, 15, 16, 31, 32 neighbours and long rows
+    rs = np.random.RandomState(11)
+    deg = rs.choice([0, 1, 2, 7, 14, 15, 16, 17, 30, 31, 32, 33, 200], size=V, p=[.04, .08, .1, .2, .1, .1, .1, .08, .05, .05, .04, .03, .03]).astype(np.int64)
+    indptr = np.concatenate([[0], np.cumsum(deg)])
+    indices = rs.randint(0, V, size=int(indptr[-1])).astype(np.int32)
+    indices[rs.rand(len(indices)) < 0.002] = -1                          # the reference skips negative neighbour ids (Kernels.cu:411)
+    B, fan = 300, [10, 5, 3]
+    seeds = dict(train=[(ds.train, ds.labels[ds.train])])
+    eng = K.Engine(indptr, indices, ds.features, V, spec.F, seeds, B, fan)
+    eng.alloc_features()
+    W = C.c_int32(0)
+    hp = L.GPUGraphStorage_GetHeadTable(eng.graph, 0, C.byref(W))
+    if mode == "0":
+        assert not hp
+    else:
+        assert hp and W.value == {"16": 16, "32": 32, "auto": 16 if indptr[-1] <= 24 * V else 32}[mode]
+        w = W.value
+        head = K.read_dev(hp, np.int32, V * w).reshape(V, w)
+        assert np.array_equal(head[:, 0], deg.astype(np.int32))
+        small = np.flatnonzero(deg < w)
+        for v in small[rs.choice(len(small), 400, replace=False)]:
+            assert np.array_equal(head[v, 1:1 + deg[v]], indices[indptr[v]:indptr[v + 1]]) and (head[v, 1 + deg[v]:] == 0).all()
+        big = np.flatnonzero(deg >= w)
+        start = head[big, 1].astype(np.uint32).astype(np.int64) | (head[big, 2].astype(np.int64) << 32)
+        assert np.array_equal(start, indptr[big])
+    orc = oracle.OracleRunner(indptr, indices, ds.features, V, spec.F, B, fan)
+    for it in (0, 2):
+        ref = orc.run_batch(ds.train, ds.labels[ds.train], it)
+        eng.run_batch(0, it)
+        assert_batch_equal(ref, eng.result(0))
+    eng.close()
+
+
 @pytest.mark.parametrize("F,lanes", [(100, "auto"), (100, "1"), (36, "1"), (7, "auto"), (52, "1")])
 def test_padded_row_pitch_gathers_the_same_bytes(K, oracle, synth, F, lanes, monkeypatch):
     """an HBM feature table whose rows are padded to a 128-byte-aligned pitch (legion_row_pitch; F = 100 ->

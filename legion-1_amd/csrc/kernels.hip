@@ -207,29 +207,24 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
             if (src >= 0) {
                 const int64_t* ip = a.csr.indptr + src;
                 const int32_t* ix = a.csr.indices;
-                int64_t start;
-                if (PARTITIONED && !PRESC) {
-                    const int8_t owner = a.csr.topo_owner[src]; // FindTopo fused (GPUCache.cu:434-443)
-                    if (owner >= 0) {   // cached row: chunk tables of the owner's fragment (local HBM or xGMI peer)
-                        const int32_t row = a.csr.topo_row[src];
-                        ip = a.csr.frag_indptr[owner * a.csr.ip_nch + (row >> a.csr.row_shift)] + (row & ((1 << a.csr.row_shift) - 1));
-                        start = ip[0];
-                        ix = a.csr.frag_indices[owner * a.csr.ix_nch + (int32_t)(start >> a.csr.edge_shift)];
-                        rowp = ix + (start & ((1ll << a.csr.edge_shift) - 1));
-                    } else {
-                        start = ip[0];
-                        rowp = ix + start;
-                    }
+                int8_t owner = -1;
+                if (PARTITIONED && !PRESC) owner = a.csr.topo_owner[src]; // FindTopo fused (GPUCache.cu:434-443)
+                if (owner >= 0) {   // cached row: chunk tables of the owner's fragment (local HBM or xGMI peer)
+                    const int32_t row = a.csr.topo_row[src];
+                    ip = a.csr.frag_indptr[owner * a.csr.ip_nch + (row >> a.csr.row_shift)] + (row & ((1 << a.csr.row_shift) - 1));
+                    const int64_t start = ip[0];
+                    ix = a.csr.frag_indices[owner * a.csr.ix_nch + (int32_t)(start >> a.csr.edge_shift)];
+                    rowp = ix + (start & ((1ll << a.csr.edge_shift) - 1));
                     deg = (int32_t)(ip[1] - start); // int32 truncation as in Kernels.cu:393,396
                 } else if (!PRESC && a.csr.head) {
-                    // head table: degree and -- for rows that fit -- the neighbours themselves in ONE line
+                    // head table of the whole-CSR copy: degree and -- for rows that fit -- the neighbours themselves in ONE line
                     const int32_t* hp = a.csr.head + ((int64_t)src << a.csr.head_shift);
                     const int4 h4 = *reinterpret_cast<const int4*>(hp);        // entries are 64 / 128-byte aligned: one 16-byte load
                     deg = h4.x;
                     if (deg < (1 << a.csr.head_shift)) rowp = hp + 1;
                     else rowp = ix + (int64_t)(((uint64_t)(uint32_t)h4.z << 32) | (uint32_t)h4.y);
                 } else {
-                    start = ip[0];
+                    const int64_t start = ip[0];
                     rowp = ix + start;
                     deg = (int32_t)(ip[1] - start);
                 }

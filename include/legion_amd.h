@@ -142,8 +142,9 @@ int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g);
 /* Head tables over the HBM copies of the whole CSR (built by Build() for a device-resident CSR and by ReplicateToDevices()):
  * one 64- or 128-byte entry per node holding its degree and -- when they fit -- its neighbours, so that the sampler reads ONE
  * random line per low-degree source row instead of the indptr pair and the adjacency line (MI355X: HBM capacity traded for
- * random accesses; papers100M shape: 7.1 GB).  $LEGION_HEAD_TABLE = auto | 0 | 16 | 32 (ints per entry).  Same draws, same
- * neighbours: bit-identical output.  Returns the bytes per device (0: none built). */
+ * random accesses; papers100M shape: 7.1 GB).  $LEGION_HEAD_TABLE = 0 (default) | auto | 16 | 32 (ints per entry).  Same draws,
+ * same neighbours: bit-identical output.  An option, not the default: it is worth 1-2 % of the sampler at the papers100M and
+ * products shapes and costs 4-9 % at uk-union 3-hop (profiles/r03_sampler.md).  Returns the bytes per device (0: none built). */
 int64_t GPUGraphStorage_BuildHeadTables(GPUGraphStorage* g);
 int32_t* GPUGraphStorage_GetHeadTable(const GPUGraphStorage* g, int32_t dev_id, int32_t* ints_per_entry);
 int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g);

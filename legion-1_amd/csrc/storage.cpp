@@ -113,13 +113,16 @@ void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info)
 }
 
 // Head tables (CsrTables::head) over the HBM copies of the whole CSR: one per distinct physical device among the local logical
-// GPUs.  $LEGION_HEAD_TABLE = auto (default: 64-byte entries up to a mean degree of 24, else 128-byte; skipped when it would not
-// leave 20 % of the free HBM) | 0 (off) | 16 | 32 (ints per entry).  Returns the bytes allocated per device (0: none).
+// GPUs.  $LEGION_HEAD_TABLE = 0 (default: off) | auto (64-byte entries up to a mean degree of 24, else 128-byte; skipped when it
+// would not leave 20 % of the free HBM) | 16 | 32 (ints per entry).  Returns the bytes allocated per device (0: none).
+// Off by default: measured on MI355X (profiles/r03_sampler.md) it buys 1 % of the sampler at the papers100M shape and 2.4 % at
+// products 3-hop for 7 GB / 0.3 GB of HBM, and costs 4-9 % at uk-union 3-hop (128-byte entries) -- the sampler is not bound by
+// the number of row accesses.
 int64_t GPUGraphStorage_BuildHeadTables(GPUGraphStorage* g)
 {
     if (!g || g->node_num <= 0) return 0;
     const char* e = getenv("LEGION_HEAD_TABLE");
-    const std::string mode = e ? e : "auto";
+    const std::string mode = e ? e : "0";
     if (mode == "0" || mode == "off") return 0;
     int shift = (g->edge_num > 24ll * g->node_num) ? 5 : 4;
     if (mode == "16") shift = 4;

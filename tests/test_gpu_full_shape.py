@@ -172,14 +172,16 @@ def test_uk_union_sharded_csr_full_shape(K, synth, G, mode, host_spill):
         L.host_free_space(host)
 
 
-def test_papers100m_link_prediction_full_shape(K, synth):
+@pytest.mark.parametrize("world,rank", [(2, 1), (8, 5)])
+def test_papers100m_link_prediction_full_shape(K, synth, world, rank):
     """Config 5: [src | pos | neg] seed batches at the papers100M shape (11.1 M triples generated on the GPU by
-    legion_synth_lp_seeds, the list of logical GPU 1 of 2: triples dealt by src % 2), 3-hop."""
+    legion_synth_lp_seeds; the list of logical GPU `rank` of `world`: triples dealt by src % world -- 2 GPUs, and the 8 GPUs
+    BASELINE.json states), 3-hop."""
     import torch
     L = K.lib()
     spec, indptr, indices, feats, E = device_graph(K, synth, "papers100M")
     dev = indptr.device
-    B, fan, world, rank = 7998, [25, 10, 5], 2, 1
+    B, fan = 7998, [25, 10, 5]
     k = B // 3
     tr = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
     L.legion_synth_seed_ids(None, tr.data_ptr(), 0, spec.n_train, spec.V, spec.M2, spec.C2, 1, 0)
@@ -191,7 +193,7 @@ def test_papers100m_link_prediction_full_shape(K, synth):
     L.legion_synth_lp_seeds(None, seeds.data_ptr(), srcs.data_ptr(), triple_no.data_ptr(), n_tr, B, indptr.data_ptr(), indices.data_ptr(), spec.V, 1)
     torch.cuda.synchronize()
     K.check()
-    assert n_tr > 5_000_000
+    assert n_tr > 10_000_000 // world
     lab = torch.empty(spec.V, dtype=torch.int32, device=dev)
     L.legion_synth_labels(None, lab.data_ptr(), 0, spec.V, spec.classes)
     my_lab = lab[seeds.long()].contiguous()

@@ -782,6 +782,71 @@ def test_randomised_differential(K, oracle, seed):
     eng.close()
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("LEGION_STRESS_CACHE_N", "8")))))
+def test_randomised_clique_cache_differential(K, oracle, seed, monkeypatch):
+    """The cached path under random configurations (S5 / S6 / S8 / S9): random graph, feature width (odd, not a multiple of 4, not a
+    whole number of 128-byte lines), hop count and fan-outs, clique size Kg in {1, 2, 4, 8} with one or two cliques, forced node / edge
+    capacities from 0 to "more than V", shard / fragment chunk sizes, head table on or off, in-kernel or bulk-copy peer gather --
+    pre-sampling hotness, ranking, id -> slot maps and every steady-state batch of every GPU bit-identical to the oracle."""
+    rng = np.random.RandomState(7000 + seed)
+    L = K.lib()
+    V = int(rng.choice([700, 2500, 9000]))
+    F = int(rng.choice([1, 4, 7, 20, 36, 100, 128]))
+    deg = rng.geometric(0.12, size=V) - 1
+    hubs = rng.randint(0, V, size=max(1, V // 80))
+    deg[hubs] = rng.randint(40, 300, size=len(hubs))
+    indptr = np.zeros(V + 1, np.int64)
+    indptr[1:] = np.cumsum(deg)
+    nbr = np.where(rng.rand(int(indptr[-1])) < 0.4, rng.choice(hubs, size=int(indptr[-1])), rng.randint(0, V, size=int(indptr[-1])))
+    nbr[rng.rand(len(nbr)) < 0.01] = -1
+    indices = nbr.astype(np.int32)
+    feats = rng.standard_normal((V, F)).astype(np.float32)
+    labels = rng.randint(0, 9, size=V).astype(np.int32)
+    Kg, mode = [(1, 0), (2, 1), (4, 2), (8, 3)][int(rng.randint(4))]
+    G = Kg * (2 if (Kg <= 4 and rng.rand() < 0.4) else 1)
+    hops = int(rng.randint(1, 4))
+    fan = [int(rng.randint(2, 9)) for _ in range(hops)]
+    train = rng.permutation(V)[:max(G * 40, V // 3)].astype(np.int32)
+    parts = oracle.split_seeds(train, G)
+    B = int(rng.randint(8, min(len(p) for p in parts)))
+    steps = max(1, min((len(p) - 1) // B for p in parts))
+    for name, val in (("LEGION_SHARD_CHUNK_BYTES", rng.choice(["20000", "150000", None])), ("LEGION_HEAD_TABLE", rng.choice(["0", "auto"])),
+                      ("LEGION_PEER_GATHER", rng.choice(["exchange", None]))):
+        if val is None:
+            monkeypatch.delenv(name, raising=False)
+        else:
+            monkeypatch.setenv(name, str(val))
+    cap_n = int(rng.choice([0, 1, V // (3 * Kg), V // Kg + 1, V]))
+    cap_e = int(rng.choice([0, 1, V // (4 * Kg), V // Kg + 1]))
+    seeds = dict(train=[(p, labels[p]) for p in parts])
+    eng = make_engine(K, (V, F, indptr, indices, feats), B, fan, G=G, seeds=seeds, train_step=steps)
+    orcs = [oracle.OracleRunner(indptr, indices, feats, V, F, B, fan, partition_count=G) for _ in range(G)]
+    for g in range(G):
+        for it in range(steps):
+            eng.run_batch(g, it, is_presc=True)
+            assert_batch_equal(orcs[g].run_batch(parts[g], labels[parts[g]], it, is_presc=True), eng.result(g, with_features=False))
+    eng.build_cache(cache_agg_mode=mode, node_capacity=cap_n, edge_capacity=cap_e, train_step=steps)
+    for Ki in range(G // Kg):
+        members = list(range(Ki * Kg, (Ki + 1) * Kg))
+        _, QF = oracle.candidate_selection([orcs[m].node_access_time for m in members], V)
+        _, QT = oracle.candidate_selection([orcs[m].edge_access_time for m in members], V)
+        L.SetGPUDevice(Ki * Kg)
+        assert np.array_equal(K.read_dev(L.GPUCache_GetQF(eng.cache, Ki), np.int32, V), QF)
+        assert np.array_equal(K.read_dev(L.GPUCache_GetQT(eng.cache, Ki), np.int32, V), QT)
+        for m in members:
+            if cap_n > 0:
+                orcs[m].set_feature_cache(QF, cap_n, Kg)
+            if cap_e > 0:
+                orcs[m].set_topo_cache(QT, cap_e, Kg, Ki)
+    for g in range(G):
+        n_b = (len(parts[g]) + B - 1) // B
+        for it in [0, n_b - 1, int(rng.randint(n_b))]:          # incl. the short last batch of the shard
+            ref = orcs[g].run_batch(parts[g], labels[parts[g]], it)
+            eng.run_batch(g, it, per_level=bool(rng.randint(2)))
+            assert_batch_equal(ref, eng.result(g))
+    eng.close()
+
+
 @pytest.mark.parametrize("V,B,fan", [(3000, 1000, [25, 10, 5]), (400, 400, [12, 12, 6, 3])])
 def test_heavy_duplicate_contention(K, oracle, V, B, fan):
     """Far more slots than nodes (1.25 M slots over 3000 nodes: every node is claimed hundreds of times per hop from

@@ -749,7 +749,7 @@ def test_overlapped_two_stream_schedule(K, oracle, small_ds):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("LEGION_STRESS_N", "12")))))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("LEGION_STRESS_N", "24")))))
 def test_randomised_differential(K, oracle, seed):
     """Random graphs (hubs, isolated nodes, -1 entries, self loops), random fan-outs / batch sizes / hop counts,
     duplicate and repeated seeds, several consecutive batches on one engine: HIP == oracle, bit for bit."""
@@ -782,7 +782,7 @@ def test_randomised_differential(K, oracle, seed):
     eng.close()
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("LEGION_STRESS_CACHE_N", "8")))))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("LEGION_STRESS_CACHE_N", "16")))))
 def test_randomised_clique_cache_differential(K, oracle, seed, monkeypatch):
     """The cached path under random configurations (S5 / S6 / S8 / S9): random graph, feature width (odd, not a multiple of 4, not a
     whole number of 128-byte lines), hop count and fan-outs, clique size Kg in {1, 2, 4, 8} with one or two cliques, forced node / edge

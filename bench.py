@@ -349,6 +349,14 @@ class LegGuard:
         try:
             ok, res = True, None
             try:
+                # test hook (tests/test_gpu_bench_legs.py): LEGION_BENCH_INJECT_HANG=<leg>[:<rank>] makes that rank never
+                # come back from the leg, LEGION_BENCH_INJECT_ERROR=<leg>[:<rank>] makes it raise
+                for kind in ("HANG", "ERROR"):
+                    inj = os.environ.get("LEGION_BENCH_INJECT_" + kind, "").split(":")
+                    if inj[0] == name and (len(inj) < 2 or int(inj[1]) == c.rank):
+                        if kind == "ERROR":
+                            raise RuntimeError("injected failure of leg %s on rank %d" % (name, c.rank))
+                        time.sleep(10 ** 6)
                 res = fn()
             except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
                 ok, res = False, {"error": repr(ex)[:300]}

@@ -314,11 +314,23 @@ class LegGuard:
     (a collective or an IPC import that never returns) cannot be recovered from inside the process: rank 0 prints the line it
     has -- headline included, the leg named in "legs_failed" with the Python stack it was stuck in -- and EVERY rank leaves with
     exit code LEG_HUNG_EXIT.  The timer of a rank stays armed through the agreement all-gather and the barrier behind the leg,
-    so a rank that finished cannot be left waiting in a collective for one that hangs: its own timer ends it too."""
+    so a rank that finished cannot be left waiting in a collective for one that hangs: its own timer ends it too.
+    A leg that raises on SOME ranks only leaves the others inside the leg's collectives; the failing rank says so in the job's
+    key-value store, and a rank that is still inside the leg a few seconds after a peer reported a failure ends the same way
+    (named error, exit code LEG_HUNG_EXIT) without waiting for the whole timeout."""
+
+    PEER_GRACE_S = 5.0
 
     def __init__(self, c, line):
         self.c, self.line = c, line
         self.partial = None        # what a leg has measured so far (printed if a later part of it hangs)
+        self.store = None
+        if c.world > 1:
+            try:
+                import torch.distributed.distributed_c10d as c10d
+                self.store = c10d._get_default_store()
+            except Exception:   # noqa: BLE001 -- the plain timeout still applies
+                self.store = None
 
     def run(self, name, timeout, fn):
         import faulthandler
@@ -327,9 +339,10 @@ class LegGuard:
         main_thread = threading.main_thread().ident
         self.partial = None
 
-        def fire():
+        in_leg = [True]
+
+        def fire(msg=f"did not finish within {timeout:.0f} s"):
             try:
-                msg = f"did not finish within {timeout:.0f} s"
                 stack = "".join(traceback.format_stack(sys._current_frames().get(main_thread)))[-1500:]
                 if c.rank == 0:
                     line["legs_failed"].append({"leg": name, "error": msg, "hung": True, "stuck_at": stack})
@@ -346,6 +359,22 @@ class LegGuard:
         timer = threading.Timer(timeout, fire)
         timer.daemon = True
         timer.start()
+        key = "legion_leg_failed/" + name
+
+        def watch_peers():       # a peer that raised inside the leg will never join this rank's collectives
+            seen = None
+            while in_leg[0] and self.store is not None:
+                try:
+                    if seen is None and self.store.check([key]):
+                        seen = time.time()
+                        who = self.store.get(key).decode(errors="replace")
+                    if seen is not None and time.time() - seen > self.PEER_GRACE_S and in_leg[0]:
+                        fire("a peer failed inside the leg while this rank was still in it: " + who)
+                except Exception:   # noqa: BLE001
+                    return
+                time.sleep(0.5)
+        if self.store is not None:
+            threading.Thread(target=watch_peers, daemon=True).start()
         try:
             ok, res = True, None
             try:
@@ -360,6 +389,12 @@ class LegGuard:
                 res = fn()
             except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
                 ok, res = False, {"error": repr(ex)[:300]}
+                if self.store is not None:
+                    try:
+                        self.store.set(key, "rank %d: %s" % (c.rank, repr(ex)[:300]))
+                    except Exception:   # noqa: BLE001
+                        pass
+            in_leg[0] = False
             # every rank must agree that the leg worked before its numbers are believed
             flags = c.D.allgather_object((ok, None if ok else res["error"]), c.world)
             bad = [(i, e) for i, (f, e) in enumerate(flags) if not f]

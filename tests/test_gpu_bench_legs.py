@@ -53,3 +53,15 @@ def test_a_hung_leg_ends_every_rank_with_exit_code_3_and_the_headline_is_printed
     assert line["legs_failed"][0]["leg"] == "unified_cache" and line["legs_failed"][0]["hung"] is True
     assert "did not finish" in line["unified_cache"]["error"]
     assert "the headline line was printed" in r.stderr
+
+
+def test_a_leg_that_fails_on_one_rank_only_is_reported_within_seconds():
+    """Rank 1 raises inside `lp`, rank 0 is left in the leg's collectives: the failure travels through the job's key-value store and
+    rank 0 ends the run with the named error after a few seconds -- not after the leg's whole timeout (150 s)."""
+    import time
+    t0 = time.time()
+    r, line = _bench({"LEGION_BENCH_INJECT_ERROR": "lp:1"})
+    assert r.returncode == 3 and time.time() - t0 < 100, (r.returncode, time.time() - t0, r.stderr[-2000:])
+    f = line["legs_failed"][0]
+    assert f["leg"] == "lp" and f["hung"] is True and "rank 1" in f["error"] and "injected failure" in f["error"]
+    assert line["value"] > 0 and line["unified_cache"]["value"] > 0           # everything before the failed leg is in the line

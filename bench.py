@@ -396,13 +396,16 @@ class LegGuard:
                         pass
             in_leg[0] = False
             # every rank must agree that the leg worked before its numbers are believed
-            flags = c.D.allgather_object((ok, None if ok else res["error"]), c.world)
-            bad = [(i, e) for i, (f, e) in enumerate(flags) if not f]
-            if bad:
-                if ok:
-                    res = {"error": "failed on rank(s) %s" % [i for i, _ in bad]}
-                line["legs_failed"].append({"leg": name, "error": "; ".join("rank %d: %s" % (i, e) for i, e in bad)[:600], "hung": False})
-            c.D.barrier(c.world)
+            try:
+                flags = c.D.allgather_object((ok, None if ok else res["error"]), c.world)
+                bad = [(i, e) for i, (f, e) in enumerate(flags) if not f]
+                if bad:
+                    if ok:
+                        res = {"error": "failed on rank(s) %s" % [i for i, _ in bad]}
+                    line["legs_failed"].append({"leg": name, "error": "; ".join("rank %d: %s" % (i, e) for i, e in bad)[:600], "hung": False})
+                c.D.barrier(c.world)
+            except Exception as ex:   # noqa: BLE001 -- the peers left (they were stuck inside the leg this rank failed in): same ending
+                fire("the agreement after the leg failed (%s); this rank's own result: %s" % (repr(ex)[:200], res if not ok else "ok"))
             return res
         finally:
             timer.cancel()

@@ -42,7 +42,6 @@
 //    there is not a single device->host copy in the batch (the reference does 7).
 #include "internal.h"
 #include <hipcub/hipcub.hpp>
-#include <cstring>
 #include <mutex>
 
 namespace legion {
@@ -733,78 +732,6 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
     }
 }
 
-// Blocked gather (EXPERIMENT, $LEGION_GATHER_BLOCKED): a workgroup resolves the source address of 256 consecutive rows into LDS
-// (stage A: id -> [cache slot -> clique GPU / chunk / row ->] address, what k_row_ptrs does in a launch of its own), then copies
-// them (stage B: 16-byte chunks, U independent loads per lane in flight, no dependent load left in the copy loop).  The lookup
-// chain of one workgroup overlaps with the copies of the others on its CU.
-template <int U>
-__global__ __launch_bounds__(kBlock) void k_gather_blocked(GatherKArgs a)
-{
-    __shared__ const float* s_ptr[kBlock];
-    __shared__ int32_t s_hits[kBlock / 64];
-    const GatherArgs& g = a.g;
-    const int32_t off = g.off_idx < 0 ? 0 : g.nc[g.off_idx];
-    const int32_t rows = g.nc[g.size_idx];
-    const int32_t C = g.F / 4;
-    const int32_t nblk = (rows + kBlock - 1) / kBlock;
-    if (g.rows_seen && blockIdx.x == 0 && threadIdx.x == 0) *g.rows_seen = rows;
-    if (g.hit_stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(g.hit_stats + 1, rows);
-    const int64_t tpitch = g.table_pitch > 0 ? g.table_pitch : g.F, spitch = g.shard_pitch > 0 ? g.shard_pitch : g.F;
-    for (int32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-        const int32_t r = blk * kBlock + threadIdx.x;
-        const float* src = nullptr;
-        int32_t hit = 0;
-        if (r < rows && !(g.dst_rows > 0 && off + r >= g.dst_rows)) {
-            const int32_t id = g.sampled_ids[off + r];
-            const int32_t gidx = (id >= 0 && g.feat_map) ? g.feat_map[id] : -1;
-            if (gidx >= 0) {
-                const uint32_t didx = fdiv((uint32_t)gidx, a.div_cap);
-                const uint32_t fidx = (uint32_t)gidx - didx * (uint32_t)g.cache_capacity;
-                const float* chunk = g.shard_tab[didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
-                src = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * spitch;
-                hit = 1;
-            } else if (id >= 0 && g.table) {
-                src = g.table + (int64_t)(id % g.total_num_nodes) * tpitch;
-            }
-        }
-        s_ptr[threadIdx.x] = src;
-        if (g.hit_stats) {
-            for (int o = 32; o > 0; o >>= 1) hit += __shfl_down(hit, o);
-            if (lane_id() == 0) s_hits[wave_id()] = hit;
-        }
-        __syncthreads();
-        if (g.hit_stats && threadIdx.x == 0) {
-            int32_t h = 0;
-            for (int w = 0; w < kBlock / 64; w++) h += s_hits[w];
-            if (h) atomicAdd(g.hit_stats, h);
-        }
-        const int32_t nr = min(kBlock, rows - blk * kBlock);
-        const int32_t total = nr * C;
-        v4f* __restrict__ dst = reinterpret_cast<v4f*>(g.dst) + (int64_t)(off + blk * kBlock) * C;
-        for (int32_t i0 = threadIdx.x; i0 < total; i0 += kBlock * U) {
-            const v4f* p[U];
-            v4f v[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int32_t i = i0 + u * kBlock;
-                p[u] = nullptr;
-                if (i < total) {
-                    const uint32_t row = fdiv((uint32_t)i, a.div_c);
-                    const float* base = s_ptr[row];
-                    if (base) p[u] = reinterpret_cast<const v4f*>(base) + ((uint32_t)i - row * (uint32_t)C);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (p[u]) v[u] = __builtin_nontemporal_load(p[u]);
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (p[u]) __builtin_nontemporal_store(v[u], dst + i0 + u * kBlock);
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // S5, owner-computes exchange variant (SURVEY 5 option b; one process per GPU): rows whose cache slot lives on another
 // clique member are not read in-kernel over xGMI; the requester lists them per owner, the owners gather them from their
@@ -1224,26 +1151,6 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // run long serial loops, more leave most of the grid empty (profiles/r01_gather_sweep.md).  The static row
     // bound is typically filled 15-60 %, so the grid is sized from the row count an earlier launch of this kind
     // reported (rows_seen, no host round trip), + 25 %; without a report: the bound, at most 512 workgroups per CU.
-    {   // EXPERIMENT: $LEGION_GATHER_BLOCKED=<U>[,<workgroups per CU>]  (U in 1, 2, 4, 8)
-        const char* be = getenv("LEGION_GATHER_BLOCKED");
-        if (be && atoi(be) > 0 && vec4 && !(g.row_ptr && g.row_ptr_ready) && !g.table_on_host) {
-            const int U = atoi(be);
-            const char* comma = strchr(be, ',');
-            const int per_cu = comma ? std::max(1, atoi(comma + 1)) : 8;
-            const int64_t est_rows = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
-            const int bgrid = grid_for(est_rows, kBlock, per_cu);
-            GatherKArgs b = a;
-            if (!g.feat_map) b.g.shard_tab = nullptr;
-            switch (U) {
-            case 1: k_gather_blocked<1><<<bgrid, kBlock, 0, s>>>(b); break;
-            case 2: k_gather_blocked<2><<<bgrid, kBlock, 0, s>>>(b); break;
-            case 8: k_gather_blocked<8><<<bgrid, kBlock, 0, s>>>(b); break;
-            default: k_gather_blocked<4><<<bgrid, kBlock, 0, s>>>(b); break;
-            }
-            HIP_CHECK_LAST();
-            return;
-        }
-    }
     int grid;
     if (g.row_ptr && !g.row_ptr_ready) {
         const int64_t est_rows = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;

@@ -350,13 +350,32 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
         h.in_off = ec[2]; h.n_in = nc[2]; h.slots = total; h.pad = 0;
         *hs = h;
     }
+    // the slot states of the NEXT tile of this workgroup are fetched before the current one is ranked: the loads overlap the
+    // two barriers and the stores of the current tile (a workgroup runs 1-5 tiles; the pass is a chain of short latencies)
+    int32_t nxt[S];
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const int64_t idx = (int64_t)blockIdx.x * kTile + threadIdx.x + kBlock * s;
+        nxt[s] = ((int32_t)blockIdx.x < n_tiles && idx < total) ? aux[idx] : 0;
+    }
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         bool win[S];
         int32_t rk[S];
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
-            win[s] = idx < total && aux[idx] == -1;
+            win[s] = idx < total && nxt[s] == -1;
+        }
+        {
+            const int64_t nt = (int64_t)tile + gridDim.x;
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+                const int64_t idx = nt * kTile + threadIdx.x + kBlock * s;
+                nxt[s] = (nt < n_tiles && idx < total) ? aux[idx] : 0;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
             const unsigned long long b = __ballot(win[s]);
             rk[s] = __popcll(b & lt);
             if (lane == 0) s_c[s * W + wave] = __popcll(b);

@@ -1,13 +1,13 @@
 mkdir -p gpurun_out/r03q
 cd /tmp && export TMPDIR=/tmp
-for wl in "products 25,10,5" "uk-union 25,10,5"; do
+for wl in "papers100M 25,10,5" "products 25,10,5" "uk-union 25,10,5"; do
   set -- $wl
   rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r03q/$1 -- python3 $GRAFT_REPO_ROOT/bench.py --workload $1 --fanout $2 --headline-only --cpu-baseline-seconds 0 --min-time 0.3 --steps 20 > $GRAFT_REPO_ROOT/gpurun_out/r03q/$1.json 2>/dev/null
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, collections, statistics
-for wl in ("products", "uk-union"):
+for wl in ("papers100M", "products", "uk-union"):
     f = glob.glob("gpurun_out/r03q/%s/*/*kernel_trace.csv" % wl)[0]
     seq = []
     for r in csv.DictReader(open(f)):

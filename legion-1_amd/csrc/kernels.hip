@@ -523,14 +523,6 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
         for (int32_t u = t & ~gmask; u < t; u++) { pe += a.tile_edge[u]; pn += a.tile_node[u]; }
     };
 
-    // candidates and states of the workgroup's NEXT tile are fetched while the current one is resolved and written (as in k_mark)
-    int32_t nxt_c[S], nxt_so[S];
-#pragma unroll
-    for (int s = 0; s < S; s++) {
-        const int64_t idx = (int64_t)blockIdx.x * kTile + threadIdx.x + kBlock * s;
-        nxt_c[s] = (idx < total) ? a.cand[idx] : -1;
-        nxt_so[s] = (idx < total) ? a.aux[idx] : 0;
-    }
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int32_t pre_e, pre_n;
         prefix_of(tile, pre_e, pre_n);
@@ -540,15 +532,10 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
         // ---- loads first, all S slots of the thread in flight together (nothing below this block reads global memory) ----
         int32_t c[S], so[S], dpos[S], w[S], re[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) { c[s] = nxt_c[s]; so[s] = nxt_so[s]; }
-        {
-            const int64_t nt = (int64_t)tile + gridDim.x;
-#pragma unroll
-            for (int s = 0; s < S; s++) {
-                const int64_t idx = nt * kTile + threadIdx.x + kBlock * s;
-                nxt_c[s] = (nt < n_tiles && idx < total) ? a.cand[idx] : -1;
-                nxt_so[s] = (nt < n_tiles && idx < total) ? a.aux[idx] : 0;
-            }
+        for (int s = 0; s < S; s++) {
+            const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
+            c[s] = (idx < total) ? a.cand[idx] : -1;
+            so[s] = (idx < total) ? a.aux[idx] : 0;
         }
 #pragma unroll
         for (int s = 0; s < S; s++) {

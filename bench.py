@@ -558,6 +558,19 @@ def run_leg(c, unified, headline, min_time=None):
     log = K.DevBuf((K_steps + W) * 128)  # nc/ec of every step, copied on-stream
     ev = [(L.d_event_create(), L.d_event_create()) for _ in range(K_steps)]
     pool = eng.pools[me]
+    exchange = None
+    if unified:
+        # The owner-computes exchange variant runs FIRST: it never touches a peer's memory, so its numbers exist (and are what the
+        # watchdog prints) even if the HIP-IPC import of the peers' shards -- needed by the in-kernel variant below -- never returns
+        # (that import hung in rounds 1 and 2 for single allocations of 2 GiB and more: profiles/r02_ipc_limit.md).
+        if not headline and world > 1 and not args.no_exchange_leg:
+            try:
+                exchange = exchange_leg(c, eng, me, pool, stream, steps_avail)
+            except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
+                exchange = {"error": repr(ex)[:300]}
+            if getattr(c, "guard", None) is not None:
+                c.guard.partial = dict(cache_info, what="only the exchange variant ran", exchange_variant=exchange)
+        cache_info["shard_import_s"] = import_peer_shards(D, eng, me, world)
     ev_sampled = [L.d_event_create() for _ in range(depth)]   # sampling of the batch in pipe q is complete
     ev_gathered = [L.d_event_create() for _ in range(depth)]  # gather of the batch in pipe q is complete
     used = [False] * depth
@@ -697,7 +710,7 @@ def run_leg(c, unified, headline, min_time=None):
     leg = dict(unified=unified, cache_info=cache_info, elapsed=elapsed_max, windows=[round(w * 1e3, 4) for w in win_max],
                job_edges=job_edges, job_nodes=job_nodes, job_bytes=job_bytes, samp_bytes=samp_bytes, gather_bytes=gather_bytes,
                u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, graph=None,
-               xgmi=None, exchange=None, xgmi_hw=xgmi_hw)
+               xgmi=None, exchange=exchange, xgmi_hw=xgmi_hw)
 
     # the other schedule on the very same K batches, in windows like the headline (median window): with --pipeline serial this
     # is the two-stream schedule the `legion` server runs (gather of batch i on stream 1 while batch i+1 is sampled)
@@ -734,13 +747,6 @@ def run_leg(c, unified, headline, min_time=None):
 
     if unified and not per_level:
         leg["xgmi"] = unified_cache_traffic(c, eng, me, cache_info, float(leg["g_ms"].mean()))
-    if unified and not headline and world > 1 and not args.no_exchange_leg:
-        if getattr(c, "guard", None) is not None:
-            c.guard.partial = unified_summary(c, leg)    # what the watchdog prints if the exchange leg never comes back
-        try:
-            leg["exchange"] = exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes)
-        except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
-            leg["exchange"] = {"error": repr(ex)[:300]}
     D.barrier(world)   # nobody unmaps a cache shard while a peer may still read it
     drain()
     eng.close()
@@ -748,7 +754,7 @@ def run_leg(c, unified, headline, min_time=None):
     return leg
 
 
-def exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes):
+def exchange_leg(c, eng, me, pool, stream, steps_avail):
     """The same K batches with the owner-computes exchange gather (legion-1_amd/exchange.py) instead of in-kernel peer loads:
     per batch one all-to-all of request lists and one of rows over RCCL, pre-allocated buffers, ONE host synchronisation per
     batch (the split sizes), nothing waited for at the end of a batch.  Timed in windows of K steps like every other leg."""
@@ -792,6 +798,15 @@ def exchange_leg(c, eng, me, pool, stream, steps_avail, job_edges, job_nodes):
     for i in range(max(W, 2)):      # also grows the row buffers to their steady-state size
         step(i)
     drain()
+    # census (untimed): edges and rows of the K batches the windows replay
+    o = eng.out[me][0]
+    tot_e = tot_n = 0
+    for i in range(K_steps):
+        step(W + i)
+        drain()
+        tot_e += int(o["ec"].to_numpy(np.int32, 16)[2 + H])
+        tot_n += int(o["nc"].to_numpy(np.int32, 16)[5 + 2 * H])
+    _, (job_edges, job_nodes) = D.aggregate(0.0, [tot_e, tot_n], world, device=dev)
     allocs_before = xg.allocations
     xc = None
     if c.rank == 0:
@@ -969,6 +984,16 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
     mode = {1: 0, 2: 1, 4: 2, 8: 3}[world]
     topo_rows = (int(V * args.topo_frac) // world + 1) if args.topo_frac > 0 else 0
     eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=topo_rows, train_step=args.presc_steps)
+    info = {"Kg": world, "rows_per_gpu": rows, "cached_fraction_of_V": round(rows * world / V, 4), "presc_steps": args.presc_steps,
+            "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)" if topo_rows == 0 else
+                        f"hottest {topo_rows} adjacency rows per GPU in partitioned CSR fragments (owner/row lookup fused into the sampler), rest from the replica",
+            "topo_rows_per_gpu": topo_rows}
+    return info
+
+
+def import_peer_shards(D, eng, me, world):
+    """The clique's shards / CSR fragments over HIP IPC: every rank exports its own, one importer at a time.  Needed by the in-kernel
+    peer gather (and by a partitioned sampler) only -- the owner-computes exchange never touches a peer's memory."""
     everyone = D.allgather_object(eng.export_shards(me), world)
     t_imp = time.time()
     for turn in range(world):          # one importer at a time
@@ -977,11 +1002,7 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
                 if g != me:
                     eng.import_shards(g, everyone[g])
         D.barrier(world)
-    return {"Kg": world, "rows_per_gpu": rows, "cached_fraction_of_V": round(rows * world / V, 4), "presc_steps": args.presc_steps,
-            "shard_import_s": round(time.time() - t_imp, 2),
-            "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)" if topo_rows == 0 else
-                        f"hottest {topo_rows} adjacency rows per GPU in partitioned CSR fragments (owner/row lookup fused into the sampler), rest from the replica",
-            "topo_rows_per_gpu": topo_rows}
+    return round(time.time() - t_imp, 2)
 
 
 def unified_cache_traffic(c, eng, me, cache_info, gather_ms):

@@ -61,7 +61,7 @@ def test_a_leg_that_fails_on_one_rank_only_is_reported_within_seconds():
     import time
     t0 = time.time()
     r, line = _bench({"LEGION_BENCH_INJECT_ERROR": "lp:1"})
-    assert r.returncode == 3 and time.time() - t0 < 100, (r.returncode, time.time() - t0, r.stderr[-2000:])
+    assert r.returncode == 3 and time.time() - t0 < 130, (r.returncode, time.time() - t0, r.stderr[-2000:])
     f = line["legs_failed"][0]
     assert f["leg"] == "lp" and f["hung"] is True and "rank 1" in f["error"] and "injected failure" in f["error"]
     assert line["value"] > 0 and line["unified_cache"]["value"] > 0           # everything before the failed leg is in the line

@@ -576,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             for (int q = 0; q < s * W + wave; q++) pe += s_e[q];
             const int32_t dst = c[s];
             const int32_t e = ebase + pe + re[s];
-            a.agg_src_ids[e] = dst;
+            if (!a.last_hop) a.agg_src_ids[e] = dst;   // the next hop's input list; nothing reads it after the last hop
             a.agg_dst_off[e] = dpos[s];
             // src-side offset (construct_graph, Kernels.cu:456-460) = position of the sampled neighbour
             int32_t p = so[s];

@@ -222,6 +222,8 @@ int32_t* GPUMemoryPool_GetAggSrcOf(const GPUMemoryPool* p);
 int32_t* GPUMemoryPool_GetAggDstOf(const GPUMemoryPool* p);
 int32_t* GPUMemoryPool_GetNodeCounter(const GPUMemoryPool* p);
 int32_t* GPUMemoryPool_GetEdgeCounter(const GPUMemoryPool* p);
+/* agg_src_ids (Server.cu:218-231 scratch): the neighbour id of every sampled edge = the next hop's input list.  Written for hops
+ * 1 .. H-1 only: nothing reads the last hop's ids (the COO offsets and sampled_ids carry everything a consumer gets). */
 int32_t* GPUMemoryPool_GetAggSrcId(const GPUMemoryPool* p);
 int32_t* GPUMemoryPool_GetCacheSearchBuffer(const GPUMemoryPool* p);
 char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p);

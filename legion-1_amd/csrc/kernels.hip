@@ -269,7 +269,9 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                     const unsigned long long mine = prov0 | (uint32_t)idx;
                     // (plain loads: a non-temporal hint on this pre-filter load costs +11 % of k_sample, on the neighbour load
                     // nothing, profiles/r02_sampler_experiments.md)
-                    unsigned long long cur = a.pos_map[dst];
+                    // hop 1: nearly every neighbour is new, so the pre-filter load would only add a dependent round trip in front
+                    // of the claim -- go straight to the atomic (it returns the exact entry either way)
+                    unsigned long long cur = (a.op_id == 2) ? ~0ull : a.pos_map[dst];
                     if (cur > mine) {
                         const unsigned long long old = atomicMin(a.pos_map + dst, mine);
                         if (old > mine) {

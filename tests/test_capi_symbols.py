@@ -68,3 +68,12 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(K, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         K.lib()
+
+
+def test_c_abi_survives_null_arguments():
+    """Every launcher / builder of the boundary called with NULL handles or out-of-range counts (tests/abi_null_args.py, in a child so
+    that a crash is a test failure, not the end of the session): each call returns, argument errors are sticky strings, nothing exits."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_null_args.py")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("survived"), r.stdout[-2000:] + r.stderr[-2000:]
+    assert "NewIPCEnv: device_count must be 1..8" in r.stdout and "GPUGraphStorage_Build: null argument" in r.stdout

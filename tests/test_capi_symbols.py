@@ -75,5 +75,5 @@ def test_c_abi_survives_null_arguments():
     that a crash is a test failure, not the end of the session): each call returns, argument errors are sticky strings, nothing exits."""
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_null_args.py")], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0 and r.stdout.strip().endswith("survived"), r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "survived" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "NewIPCEnv: device_count must be 1..8" in r.stdout and "GPUGraphStorage_Build: null argument" in r.stdout

@@ -318,6 +318,49 @@ def test_padded_row_pitch_gathers_the_same_bytes(K, oracle, synth, F, lanes, mon
     eng.close()
 
 
+def test_launchers_refuse_bad_arguments_and_stay_usable(K, oracle, small_ds):
+    """Argument errors of the boundary (sticky string, nothing launched, no exit) -- and the engine still produces the oracle's
+    batch afterwards: a refusal must not leave half-updated host-side bounds behind."""
+    ds = small_ds
+    B, fan = 300, [10, 5]
+    L = K.lib()
+    eng = make_engine(K, ds, B, fan)
+    pool = eng.pools[0]
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, B, fan)
+
+    def refused(text, fn):
+        L.legion_clear_error()
+        fn()
+        msg = (L.legion_last_error() or b"").decode()
+        assert text in msg, (text, msg)
+        L.legion_clear_error()
+
+    def good_batch(it):
+        eng.run_batch(0, it)
+        assert_batch_equal(orc.run_batch(ds.train, ds.labels[ds.train], it), eng.result(0))
+
+    good_batch(0)
+    refused("batch larger than the pool", lambda: L.batch_generator_kernel(None, eng.noder, eng.cache, pool, B + 1, 0, 0, 0, K.TRAINMODE))
+    good_batch(1)
+    L.batch_generator_kernel(None, eng.noder, eng.cache, pool, B, 2, 0, 0, K.TRAINMODE)
+    refused("op_id must be 2,4", lambda: L.GPU_Random_Sampling(None, eng.graph, eng.cache, pool, fan[0], 3, 0))
+    refused("op_id must be 2,4", lambda: L.GPU_Random_Sampling(None, eng.graph, eng.cache, pool, fan[0], 2 * len(fan) + 2, 0))
+    refused("fan-out exceeds what the pool was sized for", lambda: L.GPU_Random_Sampling(None, eng.graph, eng.cache, pool, 10 ** 6, 2, 0))
+    refused("op_id must be 1,3", lambda: L.get_feature_kernel(None, eng.cache, eng.noder, pool, 0, 2, 1))
+    refused("op_id must be 1,3", lambda: L.get_feature_kernel(None, eng.cache, eng.noder, pool, 0, 2 * len(fan) + 3, 1))
+    refused("needs a filled unified cache", lambda: L.legion_exchange_local(None, eng.cache, eng.noder, pool, 0))
+    L.d_stream_sync(None)
+    good_batch(2)
+    good_batch(0)
+    # a pool without scratch refuses every launcher
+    bare = L.NewGPUMemoryPool(1)
+    refused("AllocateScratch was not called", lambda: L.batch_generator_kernel(None, eng.noder, eng.cache, bare, B, 0, 0, 0, K.TRAINMODE))
+    refused("AllocateScratch was not called", lambda: L.GPU_Random_Sampling(None, eng.graph, eng.cache, bare, fan[0], 2, 0))
+    refused("AllocateScratch was not called", lambda: L.get_feature_kernel_all(None, eng.cache, eng.noder, bare, 0, 1))
+    L.GPUMemoryPool_Delete(bare)
+    eng.close()
+
+
 def test_runner_posts_a_poisoned_pipe_when_an_operator_refuses(K, small_ds):
     """LEGION_ERR_RETURN (the tests' mode): a batch an operator refused must not leave a consumer blocked on sem_w --
     Runner_RunOnce posts the pipe with every node-counter word = -1 and keeps the error.  Here the

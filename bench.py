@@ -332,6 +332,15 @@ class LegGuard:
             except Exception:   # noqa: BLE001 -- the plain timeout still applies
                 self.store = None
 
+    def announce(self, text):
+        """A part of the running leg failed on this rank and was caught further down (run_leg keeps going with an "error" object): tell
+        the peers, which may be waiting in that part's collectives."""
+        if self.store is not None and getattr(self, "key", None):
+            try:
+                self.store.set(self.key, "rank %d: %s" % (self.c.rank, text[:300]))
+            except Exception:   # noqa: BLE001
+                pass
+
     def run(self, name, timeout, fn):
         import faulthandler
         import traceback
@@ -359,7 +368,7 @@ class LegGuard:
         timer = threading.Timer(timeout, fire)
         timer.daemon = True
         timer.start()
-        key = "legion_leg_failed/" + name
+        key = self.key = "legion_leg_failed/" + name
 
         def watch_peers():       # a peer that raised inside the leg will never join this rank's collectives
             seen = None
@@ -568,6 +577,8 @@ def run_leg(c, unified, headline, min_time=None):
                 exchange = exchange_leg(c, eng, me, pool, stream, steps_avail)
             except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
                 exchange = {"error": repr(ex)[:300]}
+                if getattr(c, "guard", None) is not None:
+                    c.guard.announce("exchange variant: " + repr(ex))
             if getattr(c, "guard", None) is not None:
                 c.guard.partial = dict(cache_info, what="only the exchange variant ran", exchange_variant=exchange)
         cache_info["shard_import_s"] = import_peer_shards(D, eng, me, world)

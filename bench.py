@@ -1073,7 +1073,7 @@ def measure_traffic_in_run(args):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               capture_output=True, text=True, timeout=240)
+                               capture_output=True, text=True, timeout=90)
             files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
             if r.returncode != 0 or not files:
                 return None

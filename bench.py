@@ -1072,10 +1072,21 @@ def measure_traffic_in_run(args):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
-            r = subprocess.run([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
-                               capture_output=True, text=True, timeout=90)
+            # own session: if a pass does not come back, the profiler AND the run under it are stopped (exactly the group started here)
+            pr = subprocess.Popen([rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env,
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=90)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
             files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
-            if r.returncode != 0 or not files:
+            if rc != 0 or not files:
                 return None
             vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
                     if "legion::k_gather" in row["Kernel_Name"] and row["Counter_Name"] == counter]

@@ -9,7 +9,9 @@ its CUDA sources cannot be built or run here, so the vectors are produced by
   * the CPU oracle (oracle/legion_oracle.c) for everything else.  Those files pin the oracle
     against regressions and pin the HIP path at the listed sizes; they are not reference outputs.
 
-Usage:  python oracle/make_golden.py        (from the repository root)
+Usage:  python oracle/make_golden.py        (from the repository root; the small fixtures, seconds)
+        python oracle/make_golden.py full   (tests/golden/full_shape_digests.json: the five BASELINE shapes at full
+                                             size, ~25 GB of host memory and a few minutes on 8 cores)
 """
 from __future__ import annotations
 
@@ -158,8 +160,80 @@ def lp_seed_lists():
     return out
 
 
+# The five BASELINE.json configurations at their full shape (bench.py's workloads; B and fan-outs as benched).
+FULL_SHAPES = [
+    dict(name="products-25,10", workload="products", fanout=[25, 10], task="node", batch=8000),
+    dict(name="products-25,10,5", workload="products", fanout=[25, 10, 5], task="node", batch=8000),
+    dict(name="papers100M-25,10,5", workload="papers100M", fanout=[25, 10, 5], task="node", batch=8000),
+    dict(name="papers100M-lp", workload="papers100M", fanout=[25, 10, 5], task="lp", batch=7998),
+    dict(name="uk-union-25,10", workload="uk-union", fanout=[25, 10], task="node", batch=8000),
+]
+
+
+def full_shape_seeds(case, spec, indptr, indices):
+    """(seed list, labels) of a FULL_SHAPES case: the training ids (1-GPU split) or the [src | pos | neg] list."""
+    train = O.synth_seed_ids(spec, 0, spec.n_train)
+    if case["task"] == "lp":
+        ds = S.Dataset(spec, indptr, indices, None, None, train, None, None)
+        train = S.lp_trainingset(ds, spec.n_train, case["batch"], seed=1)
+    return train, O.synth_labels_of(spec, train)
+
+
+def full_shape_counters(case, n_seeds):
+    """Batch 0, a middle batch and the LAST batch generator call that still returns seeds: the short one of
+    Kernels.cu:224 (size = total_cap - B * counter, read at offset size * counter) for node lists; LP lists are
+    whole batches, so there it is the last full (padded) one."""
+    B = case["batch"]
+    last = (n_seeds - 1) // B
+    return [0, last // 2, last]
+
+
+def full_shape_digests(only=None):
+    """SHA-256 of every output buffer of the canonical schedule (SERIAL oracle, lo_run_batch) at the BASELINE shapes.
+    tests/test_gpu_full_shape.py compares the HIP path with these AND with the OpenMP oracle run on the GPU box."""
+    out = {"generator": "oracle/make_golden.py full: oracle/synth_gen.c CSR (spec legion-1_amd/synth.py, skew 205) + lo_run_batch (serial)",
+           "fields": ["nc", "ec", "ids", "labels", "src_off", "dst_off"], "cases": {}}
+    graphs = {}
+    for case in FULL_SHAPES:
+        if only and case["name"] not in only:
+            continue
+        spec = S.spec_for(case["workload"])
+        if case["workload"] not in graphs:
+            graphs.clear()                      # one full-size CSR at a time (uk-union: 23 GB)
+            graphs[case["workload"]] = O.synth_csr(spec)
+        indptr, indices = graphs[case["workload"]]
+        seeds, lab = full_shape_seeds(case, spec, indptr, indices)
+        r = O.OracleRunner(indptr, indices, None, spec.V, spec.F, case["batch"], case["fanout"], with_features=False)
+        entry = {"workload": case["workload"], "fanout": case["fanout"], "task": case["task"], "batch": case["batch"],
+                 "V": spec.V, "E": int(indptr[-1]), "n_seeds": int(len(seeds)), "seeds_sha256": sha(seeds),
+                 "indptr_sha256": sha(indptr), "indices_head_sha256": sha(indices[:1 << 24]), "batches": []}
+        for counter in full_shape_counters(case, len(seeds)):
+            res = r.run_batch(seeds, lab, counter, gather=False)
+            H = len(case["fanout"])
+            entry["batches"].append({"counter": counter, "size": int(res["nc"][4]), "n_nodes": int(res["nc"][5 + 2 * H]),
+                                     "n_edges": int(res["ec"][2 + H]),
+                                     **{k + "_sha256": sha(res[k]) for k in out["fields"]}})
+            print(case["name"], entry["batches"][-1]["counter"], entry["batches"][-1]["size"], entry["batches"][-1]["n_nodes"],
+                  entry["batches"][-1]["n_edges"], flush=True)
+        out["cases"][case["name"]] = entry
+        del r
+    return out
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "full":
+        path = os.path.join(GOLD, "full_shape_digests.json")
+        data = full_shape_digests(only=sys.argv[2:] or None)
+        if sys.argv[2:] and os.path.exists(path):      # regenerate selected cases only
+            with open(path) as f:
+                old = json.load(f)
+            old["cases"].update(data["cases"])
+            data = old
+        with open(path, "w") as f:
+            json.dump(data, f, indent=1)
+        print("wrote full_shape_digests", os.path.getsize(path), "bytes")
+        return
     for name, fn in (("rng_kat", rng_kat), ("toy_batches", toy_cases), ("medium_digests", medium_digests),
                      ("schedule_table", schedule_table), ("cache_fixture", cache_fixture), ("lp_seed_lists", lp_seed_lists)):
         data = fn()

@@ -17,7 +17,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, n) for n in ("legion_oracle.c", "dgl_cpu_sampler.c")]
+    srcs = [os.path.join(_HERE, n) for n in ("legion_oracle.c", "dgl_cpu_sampler.c", "synth_gen.c")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liblegion_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -328,3 +328,30 @@ class DglSemanticsSampler:
                                C.c_int32(len(self.fanout)), C.c_uint64(rng_seed), _p(self.local_map), _p(self.nodes),
                                _p(self.src), _p(self.dst), _p(self.edge_off), _p(fo), _p(self.scratch), C.byref(ne))
         return int(n), int(ne.value)
+
+
+# ---- synthetic datasets at full shape (oracle/synth_gen.c; spec: legion-1_amd/synth.py) --------------------------
+def synth_csr(spec, skew=205):
+    """(indptr int64[V+1], indices int32[E]) of a synthetic shape, generated on the host with OpenMP."""
+    L = lib()
+    L.sg_indptr.restype = C.c_int64
+    indptr = np.empty(spec.V + 1, dtype=np.int64)
+    ladder = np.ascontiguousarray(spec.ladder, dtype=np.int32)
+    E = int(L.sg_indptr(_p(indptr), C.c_int32(spec.V), _p(ladder)))
+    indices = np.empty(E, dtype=np.int32)
+    L.sg_neighbors(_p(indices), C.c_int64(0), C.c_int64(E), C.c_uint32(spec.V), C.c_uint32(spec.M), C.c_uint32(spec.C),
+                   C.c_uint32(skew))
+    return indptr, indices
+
+
+def synth_seed_ids(spec, i0, i1):
+    out = np.empty(i1 - i0, dtype=np.int32)
+    lib().sg_seed_ids(_p(out), C.c_int64(i0), C.c_int64(i1 - i0), C.c_uint32(spec.V), C.c_uint32(spec.M2), C.c_uint32(spec.C2))
+    return out
+
+
+def synth_labels_of(spec, ids):
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    out = np.empty(len(ids), dtype=np.int32)
+    lib().sg_labels_of(_p(out), _p(ids), C.c_int64(len(ids)), C.c_int32(spec.classes))
+    return out

@@ -230,3 +230,78 @@ def test_papers100m_link_prediction_full_shape(K, synth, world, rank):
         check_batch(res, spec, synth, B, fan, indptr, indices, batch, rs, distinct_seeds=False)
     assert dup_batches > 0          # hot positives repeat inside a batch: the duplicate-seed path really ran
     eng.close()
+
+
+# ---- bit-exact parity with the oracle at the BASELINE shapes -----------------------------------------------------------
+def _full_shape_cases(workload):
+    from conftest import load_golden
+    gold = load_golden("full_shape_digests")
+    return gold["fields"], {n: c for n, c in gold["cases"].items() if c["workload"] == workload}
+
+
+@pytest.mark.parametrize("workload", ["products", "papers100M", "uk-union"])
+def test_full_shape_matches_oracle(K, oracle, synth, workload):
+    """Every BASELINE.json configuration at its full shape, bit for bit against the oracle (kernel_random_sampler_2 +
+    construct_graph + update_counter, Kernels.cu:342-463, :112-150; batch_generator incl. the short last batch, :68-96,224):
+    the CSR is generated on the GPU, copied to the host once, and the OpenMP oracle (byte-identical to the serial one,
+    tests/test_oracle_batches.py) runs batch 0, a middle batch and the last batch there; nc, ec, ids, labels, src_off and
+    dst_off must be equal word for word, AND their SHA-256 must be the digests the SERIAL oracle produced on a CSR generated
+    by oracle/synth_gen.c in the build container (tests/golden/full_shape_digests.json, `oracle/make_golden.py full`).
+    What only these sizes reach: slot indices up to 12.2 M in the pow-table RNG, positions >= 2^21, k_write's grouped LDS
+    prefix (gshift > 0) on real data, edge offsets > 2^32 (uk-union), loser -> winner chains at real contention.
+    Feature rows: every gathered row against the table row on the device (the table against the closed form on a sample)."""
+    import torch
+    from conftest import sha
+    L = K.lib()
+    fields, cases = _full_shape_cases(workload)
+    assert cases
+    spec, indptr, indices, feats, E = device_graph(K, synth, workload)
+    dev = indptr.device
+    h_indptr, h_indices = indptr.cpu().numpy(), indices.cpu().numpy()
+    rs = np.random.RandomState(11)
+    probe = rs.randint(0, spec.V, 512)
+    assert np.array_equal(feats[torch.from_numpy(probe).to(dev)].cpu().numpy(), synth.features(spec, probe))
+    tr = torch.empty(spec.n_train, dtype=torch.int32, device=dev)
+    L.legion_synth_seed_ids(None, tr.data_ptr(), 0, spec.n_train, spec.V, spec.M2, spec.C2, 1, 0)
+    lab_all = torch.empty(spec.V, dtype=torch.int32, device=dev)
+    L.legion_synth_labels(None, lab_all.data_ptr(), 0, spec.V, spec.classes)
+    torch.cuda.synchronize()
+    for name, case in cases.items():
+        B, fan, H = case["batch"], case["fanout"], len(case["fanout"])
+        assert case["V"] == spec.V and case["E"] == E and sha(h_indptr) == case["indptr_sha256"], name
+        assert sha(h_indices[:1 << 24]) == case["indices_head_sha256"], name
+        seeds = tr
+        if case["task"] == "lp":
+            k = B // 3
+            triple_no = torch.arange(spec.n_train, dtype=torch.int64, device=dev)
+            seeds = torch.empty((spec.n_train + k - 1) // k * B, dtype=torch.int32, device=dev)
+            L.legion_synth_lp_seeds(None, seeds.data_ptr(), tr.data_ptr(), triple_no.data_ptr(), spec.n_train, B, indptr.data_ptr(),
+                                    indices.data_ptr(), spec.V, 1)
+            torch.cuda.synchronize()
+            K.check()
+        my_lab = lab_all[seeds.long()].contiguous()
+        n = int(seeds.numel())
+        h_seeds, h_lab = seeds.cpu().numpy(), my_lab.cpu().numpy()
+        assert n == case["n_seeds"] and sha(h_seeds) == case["seeds_sha256"], name
+        eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), spec.V, spec.F,
+                       dict(train=[((seeds.data_ptr(), n), (my_lab.data_ptr(), n))]), B, fan, E=E)
+        eng.alloc_features()
+        orc = oracle.OracleRunner(h_indptr, h_indices, None, spec.V, spec.F, B, fan, with_features=False)
+        for want in case["batches"]:
+            counter = want["counter"]
+            eng.run_batch(0, counter)
+            res = eng.result(0)
+            ref = orc.run_batch(h_seeds, h_lab, counter, gather=False, omp=True)
+            assert_batch_equal(ref, res, keys=tuple(fields))
+            assert int(res["nc"][4]) == want["size"] and len(res["ids"]) == want["n_nodes"] and len(res["src_off"]) == want["n_edges"], (name, counter)
+            for f in fields:
+                assert sha(res[f]) == want[f + "_sha256"], (name, counter, f)
+            # S5: every row of the batch is the table row of its id
+            ids_d = torch.from_numpy(res["ids"].astype(np.int64)).to(dev)
+            step = 1 << 19
+            for r0 in range(0, len(res["ids"]), step):
+                assert np.array_equal(res["features"][r0:r0 + step], feats[ids_d[r0:r0 + step]].cpu().numpy()), (name, counter, r0)
+        eng.close()
+        del orc
+    del feats, indices, indptr
+    torch.cuda.empty_cache()

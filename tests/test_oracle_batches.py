@@ -191,3 +191,38 @@ def test_openmp_oracle_is_byte_identical_to_the_serial_one(oracle, synth):
             got = b.run_batch(ds.train, ds.labels[ds.train], it, omp=True)
             for k in ("nc", "ec", "ids", "labels", "src_off", "dst_off", "features"):
                 assert np.array_equal(ref[k], got[k]), (B, fan, it, k)
+
+
+def test_c_generator_is_the_numpy_generator(oracle, synth):
+    """oracle/synth_gen.c (host, OpenMP: the full-shape fixtures) == legion-1_amd/synth.py (numpy) bit for bit; the HIP
+    generator is compared with numpy in tests/test_gpu_parity.py."""
+    for name, scale in (("products", 0.03), ("papers100M", 0.0005), ("uk-union", 0.0004)):
+        spec = synth.spec_for(name, scale=scale)
+        ds = synth.generate(spec, with_features=False)
+        indptr, indices = oracle.synth_csr(spec)
+        assert np.array_equal(indptr, ds.indptr) and np.array_equal(indices, ds.indices)
+        assert np.array_equal(oracle.synth_seed_ids(spec, 0, spec.n_train), ds.train)
+        assert np.array_equal(oracle.synth_seed_ids(spec, spec.n_train, spec.n_train + spec.n_valid), ds.valid)
+        assert np.array_equal(oracle.synth_labels_of(spec, ds.train), ds.labels[ds.train])
+
+
+def test_full_shape_digests_products(oracle, synth):
+    """tests/golden/full_shape_digests.json (BASELINE shapes at full size, serial oracle): the two ogbn-products cases are
+    regenerated here (the only shape whose CSR takes seconds on the CPU); the OpenMP oracle must give the same digests.
+    The papers100M / uk-union cases are checked on the GPU box (tests/test_gpu_full_shape.py)."""
+    from conftest import load_golden, sha
+    gold = load_golden("full_shape_digests")
+    assert set(gold["cases"]) == {"products-25,10", "products-25,10,5", "papers100M-25,10,5", "papers100M-lp", "uk-union-25,10"}
+    spec = synth.spec_for("products")
+    indptr, indices = oracle.synth_csr(spec)
+    seeds = oracle.synth_seed_ids(spec, 0, spec.n_train)
+    lab = oracle.synth_labels_of(spec, seeds)
+    for name in ("products-25,10", "products-25,10,5"):
+        case = gold["cases"][name]
+        assert case["E"] == int(indptr[-1]) and sha(indptr) == case["indptr_sha256"] and sha(seeds) == case["seeds_sha256"]
+        r = oracle.OracleRunner(indptr, indices, None, spec.V, spec.F, case["batch"], case["fanout"], with_features=False)
+        assert [b["counter"] for b in case["batches"]] == [0, 12, 24] and case["batches"][-1]["size"] == 4615   # the short last batch
+        for i, want in enumerate(case["batches"]):
+            res = r.run_batch(seeds, lab, want["counter"], gather=False, omp=(i != 1))
+            for f in gold["fields"]:
+                assert sha(res[f]) == want[f + "_sha256"], (name, want["counter"], f)

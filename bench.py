@@ -60,8 +60,10 @@ def parse(argv=None):
     ap.add_argument("--extra-legs", default="auto",
                     help="comma list of further legs run by the same processes after the headline (+ unified) leg and reported in the same "
                          "line: lp (BASELINE config 5: link-prediction seed batches on the papers100M graph, B = 7998), uk_union (config 4: "
-                         "uk-union shape, 2-hop {25,10}, CSR sharded over the clique + capped feature cache).  auto = both when N > 1 and the "
-                         "workload is the default one, none at N = 1; 'none' disables")
+                         "uk-union shape, 2-hop {25,10}, CSR sharded over the clique + capped feature cache); N = 1 also cached_gather (config 3's FindFeat + "
+                         "gather path, 25 %% of the rows in a shard), products_2hop / products_3hop (configs 1 / 2), partitioned_csr (= uk_union on one GPU).  "
+                         "auto (default workload only) = lp, cached_gather, products_2hop, products_3hop, partitioned_csr at N = 1; lp, uk_union at N > 1; "
+                         "'none' disables")
     ap.add_argument("--extra-timeout", type=float, default=150.0, help="seconds each extra leg may take")
     ap.add_argument("--extra-min-time", type=float, default=1.0, help="--min-time of the extra legs")
     ap.add_argument("--table", default="device", choices=["device", "host"],
@@ -333,13 +335,19 @@ class LegGuard:
                 self.store = None
 
     def announce(self, text):
-        """A part of the running leg failed on this rank and was caught further down (run_leg keeps going with an "error" object): tell
-        the peers, which may be waiting in that part's collectives."""
+        """A PART of the running leg failed on this rank and was caught further down (run_leg keeps going with an "error" object): tell
+        the peers, which may be waiting in that part's collectives.  The part ends with an agreement collective (part_agreed): when every
+        rank got there -- the failure was symmetric, or the others finished the part -- the announcement is settled and the leg goes on
+        with all ranks; only a rank still stuck INSIDE the part PEER_GRACE_S after the announcement ends the run."""
         if self.store is not None and getattr(self, "key", None):
             try:
-                self.store.set(self.key, "rank %d: %s" % (self.c.rank, text[:300]))
+                self.store.set(self.key + "/part", "rank %d: %s" % (self.c.rank, text[:300]))
             except Exception:   # noqa: BLE001
                 pass
+
+    def part_agreed(self):
+        """Every rank has left the announced part (called behind that part's agreement collective)."""
+        self._part_agreed = True
 
     def run(self, name, timeout, fn):
         import faulthandler
@@ -349,8 +357,13 @@ class LegGuard:
         self.partial = None
 
         in_leg = [True]
+        self._part_agreed = False
+        fired = threading.Lock()       # timer thread and watcher thread may both get here: the line is printed once
+        hung_exit = LEG_HUNG_EXIT if c.world > 1 else 0   # N = 1: the headline and the finished legs are valid and printed, nobody waits for us
 
         def fire(msg=f"did not finish within {timeout:.0f} s"):
+            if not fired.acquire(blocking=False):
+                time.sleep(3600)       # the other thread is printing and will end the process
             try:
                 stack = "".join(traceback.format_stack(sys._current_frames().get(main_thread)))[-1500:]
                 if c.rank == 0:
@@ -364,21 +377,27 @@ class LegGuard:
                     print(json.dumps(line), flush=True)
                 faulthandler.dump_traceback(file=sys.stderr)
             finally:
-                os._exit(LEG_HUNG_EXIT)
+                os._exit(hung_exit)
         timer = threading.Timer(timeout, fire)
         timer.daemon = True
         timer.start()
         key = self.key = "legion_leg_failed/" + name
 
         def watch_peers():       # a peer that raised inside the leg will never join this rank's collectives
-            seen = None
+            seen, seen_part, who, who_part = None, None, "", ""
+            mine = "rank %d:" % c.rank
             while in_leg[0] and self.store is not None:
                 try:
                     if seen is None and self.store.check([key]):
-                        seen = time.time()
                         who = self.store.get(key).decode(errors="replace")
+                        seen = time.time() if not who.startswith(mine) else float("inf")     # never act on this rank's own announcement
+                    if seen_part is None and self.store.check([key + "/part"]):
+                        who_part = self.store.get(key + "/part").decode(errors="replace")
+                        seen_part = time.time()      # own or a peer's: what counts is whether THIS rank gets out of the part
                     if seen is not None and time.time() - seen > self.PEER_GRACE_S and in_leg[0]:
                         fire("a peer failed inside the leg while this rank was still in it: " + who)
+                    if seen_part is not None and not self._part_agreed and time.time() - seen_part > self.PEER_GRACE_S and in_leg[0]:
+                        fire("a part of the leg failed on a rank and not every rank left that part: " + who_part)
                 except Exception:   # noqa: BLE001
                     return
                 time.sleep(0.5)
@@ -420,27 +439,52 @@ class LegGuard:
             timer.cancel()
 
 
+N1_LEGS = ["lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]   # run order: graph re-use first
+NN_LEGS = ["lp", "uk_union"]
+
+
 def extra_leg_names(c):
+    """auto: at N = 1 every single-GPU-measurable BASELINE path (N1_LEGS), at N > 1 configs 5 and 4 (NN_LEGS) -- for the default
+    workload only.  An explicit comma list is run in the canonical order (legs that re-use the headline graph first)."""
     a = c.args
     if a.extra_legs == "none":
         return []
     if a.extra_legs == "auto":
-        default = (a.workload == "papers100M" and a.task == "node" and a.cache == "replicated" and a.table == "device")
-        return ["lp", "uk_union"] if (c.world > 1 and default) else []
+        default = (a.workload == "papers100M" and a.task == "node" and a.cache == "replicated" and a.table == "device" and not a.headline_only)
+        if not default:
+            return []
+        return list(N1_LEGS) if c.world == 1 else list(NN_LEGS)
     names = [x for x in a.extra_legs.split(",") if x]
-    bad = [x for x in names if x not in ("lp", "uk_union")]
+    known = N1_LEGS + ["uk_union"]
+    bad = [x for x in names if x not in known]
     if bad:
         raise SystemExit("bench.py: unknown --extra-legs %s" % bad)
-    return sorted(names)        # lp first: it re-uses the headline graph, uk_union replaces it
+    return [x for x in known if x in names]
 
 
 def extra_leg(c, name):
-    """BASELINE.json configs 5 (lp) and 4 (uk_union) in the processes of this run."""
+    """The other BASELINE.json configurations in the processes of this run, one object each in `extra_legs`:
+      lp               config 5: [src | pos | neg] seed batches on the headline graph
+      cached_gather    config 3's gather path on one GPU: --cache-frac of the feature rows in a hotness-ranked shard (Kg = world),
+                       FindFeat per row (k_row_ptrs) in front of the gather, misses from the HBM table (GPUCache.cu:387-400, Kernels.cu:687-698)
+      products_2hop    config 1's workload (the CPU-sampler baseline's) on the GPU, with its CPU legs beside it
+      products_3hop    config 2
+      partitioned_csr  config 4 on the GPUs of this run (= uk_union at N > 1): uk-union shape, {25,10}, the hottest 30 % of the adjacency
+                       rows as partitioned CSR fragments (k_sample<partitioned>), 10 % of the feature rows cached"""
     import copy
     a = copy.copy(c.args)
     c2 = copy.copy(c)
     c2.args = a
     a.min_time = c.args.extra_min_time
+
+    def adopt_graph(workload):
+        for k in ("indptr", "indices", "feats", "mine", "my_labels"):     # drop the resident graph FIRST: c2 is a shallow copy, and
+            setattr(c, k, None)                                          # 64 GB + 160 GB would otherwise be resident together
+            setattr(c2, k, None)
+        load_workload(c2, workload)
+        for k in ("spec", "pitch", "indptr", "indices", "feats", "E", "feat_ptr", "feat_loc", "host_table", "mine", "my_labels", "n_mine", "steps_avail", "gen_s"):
+            setattr(c, k, getattr(c2, k))      # the previous graph is gone: later legs see this one
+
     if name == "lp":
         # lp_sage.py:87-90: [src | pos | neg] seed thirds; triples dealt to the ranks by src % N; the graph is the headline's
         a.task, a.batch = "lp", (c.B // 3) * 3
@@ -448,16 +492,38 @@ def extra_leg(c, name):
         make_seeds(c2)
         leg = run_leg(c2, unified=False, headline=False, min_time=a.min_time)
         return leg_summary(c2, leg, "link-prediction seed batches [src | pos | neg] (lp_sage.py:87-90) on the headline graph, replicated tables")
-    # uk_union: legion_server.py:23-37 shape, 2-hop GCN fan-out; the hottest 30 % of the adjacency rows as partitioned CSR fragments
-    # over the N-GPU clique (GPU_Memory_Graph_Storage.cu:98-133), 10 % of the feature rows in the unified cache, the rest from the
+    if name == "cached_gather":
+        if not c.spec.name.startswith(c.args.workload):     # an earlier leg replaced the headline graph
+            adopt_graph(c.args.workload)
+        a.no_exchange_leg, a.topo_frac = True, 0.0
+        leg = run_leg(c2, unified=True, headline=False, min_time=a.min_time)
+        out = leg_summary(c2, leg, f"headline graph and batches; the hottest {a.cache_frac:.0%} of the feature rows in a cache shard (Kg = {c.world}), every row "
+                                   "resolved by FindFeat (k_row_ptrs: id -> slot -> shard row / table row) in front of the gather, misses from the HBM table")
+        out["gather_launch_includes"] = "k_row_ptrs + k_gather (HIP events around get_feature_kernel)"
+        return out
+    if name in ("products_2hop", "products_3hop"):
+        if not c.spec.name.startswith("products"):
+            adopt_graph("products")
+        a.workload, a.task = "products", "node"
+        a.fanout = "25,10" if name == "products_2hop" else "25,10,5"
+        c2.fan = [int(x) for x in a.fanout.split(",")]
+        c2.H = len(c2.fan)
+        leg = run_leg(c2, unified=False, headline=False, min_time=a.min_time, with_alt=True)
+        out = leg_summary(c2, leg, f"ogbn-products-shape graph, {c2.H}-hop fan-out {c2.fan}, CSR + features resident in HBM (row pitch {c2.pitch} floats)")
+        if name == "products_2hop" and c.rank == 0 and c.world == 1 and c.args.cpu_baseline_seconds > 0:
+            # BASELINE config 1 is this workload on the CPU (DGL's NeighborSampler): the CPU legs on the same graph, bounded
+            a.cpu_baseline_seconds = min(4.0, c.args.cpu_baseline_seconds)
+            try:
+                out["cpu_baseline"] = run_cpu_baseline(a, c2.spec, c2.indptr, c2.indices, c2.feats, c2.mine, c2.my_labels, c2.B, c2.fan, c2.steps_avail)
+            except Exception as ex:   # noqa: BLE001 -- reported baseline only
+                out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
+        return out
+    # uk_union / partitioned_csr: legion_server.py:23-37 shape, 2-hop GCN fan-out; the hottest 30 % of the adjacency rows as partitioned CSR
+    # fragments over the N-GPU clique (GPU_Memory_Graph_Storage.cu:98-133), 10 % of the feature rows in the unified cache, the rest from the
     # HBM replica (a pinned-host backing table of 137 GB per process is not attempted here; tests/test_gpu_full_shape.py covers it)
     a.workload, a.fanout, a.task, a.topo_frac, a.cache_frac, a.no_exchange_leg = "uk-union", "25,10", "node", 0.3, 0.10, True
     c2.fan, c2.H = [25, 10], 2
-    for k in ("indptr", "indices", "feats", "mine", "my_labels"):     # drop the headline graph FIRST: c2 is a shallow copy, and
-        setattr(c, k, None)                                          # 64 GB + 160 GB would otherwise be resident together
-    load_workload(c2, "uk-union")
-    for k in ("spec", "pitch", "indptr", "indices", "feats", "E", "feat_ptr", "feat_loc", "host_table", "mine", "my_labels", "n_mine", "steps_avail", "gen_s"):
-        setattr(c, k, getattr(c2, k))      # the headline graph is gone: later legs see this one
+    adopt_graph("uk-union")
     leg = run_leg(c2, unified=True, headline=False, min_time=a.min_time)
     return leg_summary(c2, leg, f"uk-union-shape graph, CSR sharded over the {c.world}-GPU clique (30 % of the adjacency rows in partitioned "
                                 "fragments) + 10 % of the feature rows in the unified cache, misses from the HBM replica")
@@ -469,12 +535,20 @@ def leg_summary(c, leg, what):
     g = leg["g_ms"]
     reps = max(1, len(g) // args.steps)
     ach = float(leg["gather_bytes"].sum()) * reps / (g.sum() * 1e-3) / 1e9 if len(g) else None
+    samp_us = (el / args.steps * 1e6 - float(g.mean()) * 1e3) if len(g) else None     # serial schedule: the batch minus its gather launch
+    alt = leg.get("alt") or {}
     return {"what": what, "value": round(leg["job_edges"] / el, 1), "unit": "edges/s", "ms_per_step": round(el / args.steps * 1e3, 4),
             "feature_GBps": round(leg["job_nodes"] * 4 * F / el / 1e9, 2), "batch": c.B, "fanout": c.fan, "V": c.spec.V, "E": c.E, "F": F,
             "edges_per_batch": round(leg["job_edges"] / (args.steps * c.world), 1),
             "unique_nodes_per_batch": round(leg["job_nodes"] / (args.steps * c.world), 1),
             "gather_avg_launch_us": round(float(g.mean()) * 1e3, 2) if len(g) else None,
             "gather_frac_of_hbm_peak": round(ach / HBM_PEAK_GBPS, 4) if ach else None,
+            "sampler_us_per_batch": round(samp_us, 1) if samp_us is not None else None,
+            "sampler_algorithmic_bytes_per_batch": int(leg["samp_bytes"].mean()),
+            "gather_algorithmic_bytes_per_batch": int(leg["gather_bytes"].mean()),
+            # (sampler + gather algorithmic bytes) / time / (8 TB/s x N): the whole batch against the HBM roofline
+            "pipeline_frac": round(leg["job_bytes"] / el / 1e9 / (HBM_PEAK_GBPS * c.world), 4),
+            "value_overlap": alt.get("value"), "ms_per_step_overlap": alt.get("ms_per_step"), "pipeline_frac_overlap": alt.get("pipeline_frac"),
             "windows": len(leg["windows"]), "graph_gen_s": round(c.gen_s, 2), **(leg["cache_info"] or {}), **(leg["xgmi"] or {})}
 
 
@@ -515,7 +589,7 @@ def make_seeds(c):
     c.steps_avail = max(1, (c.n_mine - 1) // c.B)  # train_step = (n-1)/B, CUDA_IPC_Service.cu:89
 
 
-def run_leg(c, unified, headline, min_time=None):
+def run_leg(c, unified, headline, min_time=None, with_alt=False):
     """W warm-up steps, then R windows of exactly K timed steps (barrier + synchronize on both sides of every
     window, max over ranks per window, median over windows).  Returns the raw numbers of the leg."""
     import torch
@@ -574,11 +648,23 @@ def run_leg(c, unified, headline, min_time=None):
         # (that import hung in rounds 1 and 2 for single allocations of 2 GiB and more: profiles/r02_ipc_limit.md).
         if not headline and world > 1 and not args.no_exchange_leg:
             try:
+                inj = os.environ.get("LEGION_BENCH_INJECT_ERROR", "").split(":")     # test hook (tests/test_gpu_bench_legs.py)
+                if inj[0] == "exchange" and (len(inj) < 2 or int(inj[1]) == rank):
+                    raise RuntimeError("injected failure of the exchange variant on rank %d" % rank)
                 exchange = exchange_leg(c, eng, me, pool, stream, steps_avail)
             except Exception as ex:  # noqa: BLE001 -- reported inside the line, never fatal
                 exchange = {"error": repr(ex)[:300]}
                 if getattr(c, "guard", None) is not None:
                     c.guard.announce("exchange variant: " + repr(ex))
+            # agree right here (under the leg's armed timer): a symmetric or recoverable failure must not cost the in-kernel
+            # numbers and the legs behind -- all ranks go on together; a rank stuck inside the exchange never gets here and
+            # the watcher ends the run (LegGuard.announce)
+            ok_x = not (isinstance(exchange, dict) and "error" in exchange)
+            flags = D.allgather_object(ok_x, world)
+            if getattr(c, "guard", None) is not None:
+                c.guard.part_agreed()
+            if ok_x and not all(flags):
+                exchange = {"error": "failed on rank(s) %s" % [i for i, f in enumerate(flags) if not f]}
             if getattr(c, "guard", None) is not None:
                 c.guard.partial = dict(cache_info, what="only the exchange variant ran", exchange_variant=exchange)
         cache_info["shard_import_s"] = import_peer_shards(D, eng, me, world)
@@ -725,7 +811,7 @@ def run_leg(c, unified, headline, min_time=None):
 
     # the other schedule on the very same K batches, in windows like the headline (median window): with --pipeline serial this
     # is the two-stream schedule the `legion` server runs (gather of batch i on stream 1 while batch i+1 is sampled)
-    if headline and not per_level and not intra and not args.headline_only:
+    if (headline or with_alt) and not per_level and not intra and not args.headline_only:
         alt_w = [window(timed=False, overlap=not overlap)]
         a_first, _ = D.aggregate(alt_w[0], [0.0], world, device=dev)
         a_reps = int(min(args.max_reps, max(1, -(-(min_time / 2) // max(a_first, 1e-6)))))
@@ -844,8 +930,14 @@ def exchange_leg(c, eng, me, pool, stream, steps_avail):
            "rows_requested_last_batch_per_gpu": round(rows_req / world, 1), "xgmi_hw_counters": hw}
     rate = rows_req / world * 4 * F / max(x_sum / world, 1e-9) / 1e9     # rows received per GPU / HIP-event time of the exchange gather
     if c.shared_device:
-        out["a2a_rows_GBps_same_device"] = round(rate, 1)
+        # one-GPU rehearsal (LEGION_BENCH_FORCE_DEVICE): the all-to-alls run over gloo, i.e. every list and every row is staged through
+        # host memory -- this checks the orchestration, it is NOT a measurement: no `value`, no rate
+        out["staged_through_host"] = True
+        out["rehearsal_ms_per_step_not_a_result"] = out.pop("ms_per_step")
+        for k in ("value", "unit", "feature_GBps", "exchange_gather_ms_per_step"):
+            out.pop(k, None)
     else:
+        out["staged_through_host"] = False
         out.update({"xgmi_recv_GBps_per_gpu": round(rate, 1), "xgmi_frac_of_peak": round(rate / XGMI_PEAK_GBPS, 4)})
     xg.close()
     for a, b in ev:

@@ -116,13 +116,19 @@ typedef struct LegionBuildInfo {
     int32_t epoch;
     int32_t raw_batch_size;
     /* extension (after the reference's fields): floats between two rows of host_float_attrs; 0 = F (dense, the reference's
-     * file layout).  A caller that builds the table itself may pad rows to legion_row_pitch(F). */
+     * file layout).  A caller that builds the table itself may pad rows to legion_row_pitch(F).  Must be 0 or >= float_attr_len,
+     * and a multiple of 4 floats whenever float_attr_len is (16-byte row alignment); Build() refuses anything else.  ZERO-INITIALISE
+     * the struct: a caller compiled against the reference's shorter BuildInfo would pass an uninitialised word here. */
     int32_t float_attr_pitch;
 } LegionBuildInfo;
 /* Row pitch (in floats) the library gives the HBM copies it owns (table replicas, cache shards): F when a row is a whole
  * number of 128-byte lines, else F rounded up to 32 floats (F = 100 -> 128: every 400-byte row read then starts on a line)
  * -- unless $LEGION_ROW_PITCH=dense.  The trainer-facing feature buffer stays dense [n, F]. */
 int32_t legion_row_pitch(int32_t F);
+/* Row pitch of the feature-cache shards: legion_row_pitch(F) when `rows` padded rows fit `feat_budget_bytes` (the feature
+ * share of the reference's cache_memory contract, GPUCache.cu:674,727: capacity = budget / (F * 4)), else F (dense);
+ * feat_budget_bytes <= 0: no budget known. */
+int32_t legion_shard_pitch(int32_t F, int64_t rows, int64_t feat_budget_bytes);
 
 /* Where a table handed to Build() lives.  The reference always uses pinned host memory read
  * by the GPUs through UVA (GPUGraphStore.cu:264-265,315).  On 288 GB parts the whole table
@@ -298,7 +304,7 @@ int GPUCache_ImportFeatureShard(GPUCache* c, int32_t dev_id, const void* handle6
  * row r % ChunkRows of chunk r / ChunkRows.  Each chunk is exported / imported on its own. */
 int32_t GPUCache_ShardChunkCount(const GPUCache* c, int32_t dev_id);
 int32_t GPUCache_ShardChunkRows(const GPUCache* c, int32_t dev_id);
-int32_t GPUCache_ShardPitch(const GPUCache* c);   /* floats between two rows of a chunk: legion_row_pitch(F) */
+int32_t GPUCache_ShardPitch(const GPUCache* c);   /* floats between two rows of a chunk: legion_shard_pitch(F, capacity, feature share of cache_memory) */
 float* GPUCache_GetShardChunk(const GPUCache* c, int32_t dev_id, int32_t chunk);
 int GPUCache_ExportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, void* handle64);
 int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, const void* handle64);

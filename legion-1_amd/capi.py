@@ -57,6 +57,7 @@ _SIGS = {
     "legion_set_device_map": (None, [i32, i32]),
     "legion_physical_device": (i32, [i32]),
     "legion_row_pitch": (i32, [i32]),
+    "legion_shard_pitch": (i32, [i32, i64, i64]),
     "GPUCache_HitSamplingDone": (None, [vp, i32, vp]),
     "legion_set_remote_device": (None, [i32, C.c_int]),
     "legion_is_remote_device": (C.c_int, [i32]),

@@ -11,8 +11,9 @@
 //    capacity*Kg > V).
 //  * CostModel: when the budget covers all features and all adjacency the reference degenerates
 //    (trans_* stay 0, GPUCache.cu:744-751); we then cache everything.  The Intel-PCM PCIe counter
-//    input is optional: NULL selects an estimate from the edge hotness (one 64-byte read per
-//    sampled edge of the pre-sampling epoch).
+//    input is optional: NULL selects an estimate from the edge hotness and the row degrees
+//    (k_topo_transactions in kernels.hip has the per-row weight).
+//  * feature shards use the line-aligned row pitch only when the padded shard fits the budget.
 #include "internal.h"
 
 #include <algorithm>
@@ -316,7 +317,92 @@ void GPUCache_SetCapacity(GPUCache* c, int32_t node_capacity, int32_t edge_capac
     c->forced_edge_capacity = edge_capacity;
 }
 
-// CostModel, GPUCache.cu:661-767
+// ---- CostModel, GPUCache.cu:661-767 --------------------------------------------------------------------------------
+// What the reference computes, per clique: a budget of M = cache_memory * Kg bytes is split between adjacency rows
+// (share alpha) and feature rows (share 1 - alpha) in 100 steps; for every split the PCIe transactions the cached rows
+// would have saved during the pre-sampling epoch are estimated from the hotness curves, and the best split decides the
+// two capacities.  The float arithmetic, its evaluation order and the two log lines are the observable contract (the
+// oracle restates them from the reference); how the curves are held and walked is ours.
+} // extern "C"
+namespace {
+
+// Inclusive prefix sums, in ranking order, of: node hotness, edge hotness, adjacency bytes of the ranked rows
+struct HotnessCurves {
+    std::vector<uint64_t> node, edge, edge_bytes;
+    uint64_t node_total() const { return node.back(); }
+    uint64_t edge_total() const { return edge.back(); }
+    uint64_t adjacency_bytes() const { return edge_bytes.back(); }
+};
+
+// scan on the device (hipCUB), one staging buffer
+HotnessCurves load_curves(const GPUCache* c, int clique, const GPUGraphStorage* graph, int32_t V, uint64_t* topo_trans_estimate)
+{
+    HotnessCurves h;
+    h.node.resize(V); h.edge.resize(V); h.edge_bytes.resize(V);
+    uint64_t *d_in = nullptr, *d_out = nullptr;
+    HIP_CHECK(hipMalloc(&d_in, (size_t)V * sizeof(uint64_t)));
+    HIP_CHECK(hipMalloc(&d_out, (size_t)V * sizeof(uint64_t)));
+    auto fetch = [&](const uint64_t* src, std::vector<uint64_t>& dst) {
+        inclusive_scan_u64(nullptr, src, d_out, V);
+        HIP_CHECK(hipMemcpy(dst.data(), d_out, (size_t)V * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    };
+    fetch((const uint64_t*)c->AF[clique], h.node);
+    fetch((const uint64_t*)c->AT[clique], h.edge);
+    launch_edge_mem(nullptr, c->QT[clique], d_in, V, graph->csr_node_index_cpu);   // GetEdgeMem, GPUCache.cu:35-41
+    fetch(d_in, h.edge_bytes);
+    if (topo_trans_estimate) {
+        // PCM-free input: 64-byte transactions of the pre-sampling epoch's adjacency reads, from our own
+        // hotness counters -- deterministic, no MSR access.  See topo_transactions_of() for the per-row weight.
+        launch_topo_transactions(nullptr, c->QT[clique], (const uint64_t*)c->AT[clique], d_in, V, graph->csr_node_index_cpu);
+        inclusive_scan_u64(nullptr, d_in, d_out, V);
+        HIP_CHECK(hipMemcpy(topo_trans_estimate, d_out + (V - 1), sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    HIP_CHECK(hipFree(d_in));
+    HIP_CHECK(hipFree(d_out));
+    return h;
+}
+
+// transactions the `rows` hottest rows account for, out of `total` (GPUCache.cu:745,749: total * 1.0 / all * prefix, then float)
+inline float saved_by(uint64_t total, const std::vector<uint64_t>& prefix, int32_t rows)
+{
+    const uint64_t covered = rows > 0 ? prefix[rows - 1] : 0;   // the reference reads prefix[-1] at rows == 0
+    return (float)((double)total * 1.0 / (double)prefix.back() * (double)covered);
+}
+
+struct BudgetSplit { int64_t step; float transactions, feat_rows_per_gpu, topo_rows_per_gpu; };
+
+// the alpha sweep of GPUCache.cu:721-761: split point s gives s budget steps to the adjacency and the rest to the features
+BudgetSplit best_split(const HotnessCurves& h, int32_t V, int32_t F, int Kg, int64_t budget, uint64_t topo_trans, uint64_t feat_trans)
+{
+    int64_t step_bytes = (int64_t)((double)budget * MIN_INTERVAL);
+    if (step_bytes < 1) step_bytes = 1;
+    const int64_t n_steps = (budget - 1) / step_bytes + 1;
+    const uint64_t table_bytes = (uint64_t)V * F * sizeof(float);
+    const int64_t rows_per_step = step_bytes / (int64_t)(F * sizeof(float));
+    // what s steps of budget buy on either side (rows per GPU kept as float: the reference stores them in a float vector)
+    std::vector<float> topo_saved(n_steps + 1, 0.f), topo_rows(n_steps + 1, 0.f), feat_saved(n_steps + 1, 0.f), feat_rows(n_steps + 1, 0.f);
+    for (int64_t s = 0; s < n_steps; s++) {
+        const int64_t bytes = s * step_bytes;
+        const int32_t nf = (uint64_t)bytes > table_bytes ? V : (int32_t)((s + 1) * rows_per_step);
+        const int32_t nt = (uint64_t)bytes > h.adjacency_bytes()
+                               ? V : (int32_t)(std::lower_bound(h.edge_bytes.begin(), h.edge_bytes.end(), (uint64_t)bytes) - h.edge_bytes.begin());
+        if (nt < V) { topo_saved[s] = saved_by(topo_trans, h.edge, nt); topo_rows[s] = (float)(nt / Kg); }   // "everything fits" keeps 0: :744-751
+        if (nf < V) { feat_saved[s] = saved_by(feat_trans, h.node, nf); feat_rows[s] = (float)(nf / Kg); }
+    }
+    // first maximum over s in [0, n_steps] with the end points pinned to 0 (std::max_element over trans_of_total, :757-760)
+    BudgetSplit best{0, 0.f, 0.f, 0.f};
+    for (int64_t s = 1; s < n_steps; s++) {
+        const float t = topo_saved[s] + feat_saved[n_steps - 1 - s];
+        if (t > best.transactions) { best.step = s; best.transactions = t; }
+    }
+    best.feat_rows_per_gpu = feat_rows[n_steps - 1 - best.step];
+    best.topo_rows_per_gpu = topo_rows[best.step];
+    return best;
+}
+
+} // namespace
+extern "C" {
+
 void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPUGraphStorage* graph,
                         const uint64_t* counters, int32_t train_step)
 {
@@ -336,76 +422,43 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
             continue;
         }
         DeviceGuard guard(home);
-        std::vector<uint64_t> h_node_prefix(V), h_edge_prefix(V), h_edge_mem_prefix(V);
-        {
-            uint64_t* d_tmp = nullptr;
-            uint64_t* d_mem = nullptr;
-            HIP_CHECK(hipMalloc(&d_tmp, (size_t)V * sizeof(uint64_t)));
-            HIP_CHECK(hipMalloc(&d_mem, (size_t)V * sizeof(uint64_t)));
-            inclusive_scan_u64(nullptr, (const uint64_t*)c->AF[i], d_tmp, V);
-            HIP_CHECK(hipMemcpy(h_node_prefix.data(), d_tmp, (size_t)V * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            inclusive_scan_u64(nullptr, (const uint64_t*)c->AT[i], d_tmp, V);
-            HIP_CHECK(hipMemcpy(h_edge_prefix.data(), d_tmp, (size_t)V * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            launch_edge_mem(nullptr, c->QT[i], d_mem, V, graph->csr_node_index_cpu);
-            inclusive_scan_u64(nullptr, d_mem, d_tmp, V);
-            HIP_CHECK(hipMemcpy(h_edge_mem_prefix.data(), d_tmp, (size_t)V * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            HIP_CHECK(hipFree(d_tmp));
-            HIP_CHECK(hipFree(d_mem));
-        }
-        const int max_payload_size = CLS;
-        const int64_t total_mem = c->cache_memory * Kg;
-        const uint64_t feat_bytes = (uint64_t)V * F * sizeof(float);
+        uint64_t topo_trans = 0;
+        const HotnessCurves h = load_curves(c, i, graph, V, counters ? nullptr : &topo_trans);
+        if (counters) topo_trans = counters[0] + counters[1];       // the two Intel-PCM PCIe read counters (Server.cu:100,108)
+        const int64_t budget = c->cache_memory * Kg;
         // MI355X extension: the budget covers everything -> cache everything (see header comment)
-        if ((uint64_t)total_mem >= feat_bytes + h_edge_mem_prefix[V - 1]) {
+        if ((uint64_t)budget >= (uint64_t)V * F * sizeof(float) + h.adjacency_bytes()) {
             c->node_capacity.push_back(V / Kg + 1);
             c->edge_capacity.push_back(V / Kg + 1);
-            c->alpha.push_back((double)h_edge_mem_prefix[V - 1] / (double)total_mem);
+            c->alpha.push_back((double)h.adjacency_bytes() / (double)budget);
             std::cout << "Budget covers all data: caching everything\n";
             continue;
         }
-        int64_t memory_step = (int64_t)((double)(c->cache_memory * Kg) * MIN_INTERVAL);
-        if (memory_step < 1) memory_step = 1;
-        uint64_t total_trans_of_topo;
-        if (counters) total_trans_of_topo = counters[0] + counters[1];
-        else total_trans_of_topo = h_edge_prefix[V - 1]; // PCM-free estimate
-        uint64_t total_trans_of_feat = 0;
-        // The reference sums cache_controller_[j]->MaxIdNum() for j < Kg -- the members of the FIRST clique -- for every
-        // clique i (GPUCache.cu:677-680: index j, not i * Kg + j).  Restated as is: the capacities of cliques >= 1 depend
-        // on it whenever the GPUs saw different batch sizes.  (A member another process drives: this clique's home GPU.)
+        // Feature transactions of the epoch.  The reference sums cache_controller_[j]->MaxIdNum() for j < Kg -- the members
+        // of the FIRST clique -- for every clique i (GPUCache.cu:677-680: index j, not i * Kg + j).  Restated as is: the
+        // capacities of cliques >= 1 depend on it whenever the GPUs saw different batch sizes.  (A member another process
+        // drives: this clique's home GPU.)
+        uint64_t feat_trans = 0;
         for (int j = 0; j < Kg; j++)
-            total_trans_of_feat += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, is_remote_device(j) ? home : j) * train_step * F * (int64_t)sizeof(float)) / max_payload_size);
-
-        int64_t current_mem = 0;
-        const int64_t steps = (total_mem - 1) / memory_step + 1;
-        int64_t current_steps = 0;
-        int32_t node_num_topo = 0, node_num_feat = 0;
-        std::vector<float> trans_of_topo(steps + 1, 0), trans_of_feat(steps + 1, 0), cap_of_topo(steps + 1, 0),
-            cap_of_feat(steps + 1, 0), trans_of_total(steps + 1, 0);
-        for (; current_mem < total_mem; current_mem += memory_step) {
-            if ((uint64_t)current_mem > feat_bytes) node_num_feat = V;
-            else node_num_feat = (int32_t)((current_steps + 1) * (memory_step / (int64_t)(F * sizeof(float))));
-            if ((uint64_t)current_mem > h_edge_mem_prefix[V - 1]) node_num_topo = V;
-            else node_num_topo = (int32_t)(std::lower_bound(h_edge_mem_prefix.begin(), h_edge_mem_prefix.end(), (uint64_t)current_mem) - h_edge_mem_prefix.begin());
-            if (node_num_topo < V) {
-                uint64_t pref = node_num_topo > 0 ? h_edge_prefix[node_num_topo - 1] : 0; // reference reads [-1] at 0
-                trans_of_topo[current_steps] = (float)(total_trans_of_topo * 1.0 / h_edge_prefix[V - 1] * pref);
-                cap_of_topo[current_steps] = (float)(node_num_topo / Kg);
-            }
-            if (node_num_feat < V) {
-                uint64_t pref = node_num_feat > 0 ? h_node_prefix[node_num_feat - 1] : 0;
-                trans_of_feat[current_steps] = (float)(total_trans_of_feat * 1.0 / h_node_prefix[V - 1] * pref);
-                cap_of_feat[current_steps] = (float)(node_num_feat / Kg);
-            }
-            current_steps++;
-        }
-        for (int64_t sidx = 1; sidx < steps; sidx++) trans_of_total[sidx] = trans_of_topo[sidx] + trans_of_feat[steps - 1 - sidx];
-        const int64_t max_sidx = std::max_element(trans_of_total.begin(), trans_of_total.end()) - trans_of_total.begin();
-        std::cout << "Alpha: " << (max_sidx * MIN_INTERVAL) << " Transactions: " << trans_of_total[max_sidx] << std::endl;
-        c->node_capacity.push_back((int32_t)(cap_of_feat[steps - 1 - max_sidx] + 1));
-        c->edge_capacity.push_back((int32_t)(cap_of_topo[max_sidx] + 1));
-        c->alpha.push_back(max_sidx * MIN_INTERVAL);
-        std::cout << "Feat capacity " << cap_of_feat[steps - 1 - max_sidx] << " topo capacity " << cap_of_topo[max_sidx] << std::endl;
+            feat_trans += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, is_remote_device(j) ? home : j) * train_step * F * (int64_t)sizeof(float)) / CLS);
+        const BudgetSplit best = best_split(h, V, F, Kg, budget, topo_trans, feat_trans);
+        std::cout << "Alpha: " << (best.step * MIN_INTERVAL) << " Transactions: " << best.transactions << std::endl;
+        c->node_capacity.push_back((int32_t)(best.feat_rows_per_gpu + 1));
+        c->edge_capacity.push_back((int32_t)(best.topo_rows_per_gpu + 1));
+        c->alpha.push_back(best.step * MIN_INTERVAL);
+        std::cout << "Feat capacity " << best.feat_rows_per_gpu << " topo capacity " << best.topo_rows_per_gpu << std::endl;
     }
+}
+
+// Row pitch of the feature shards.  The shards are the bytes `cache_memory` pays for (the reference's contract: dense rows,
+// capacity = budget / (F * 4), GPUCache.cu:727), so the line-aligned pitch of legion_row_pitch (F = 100: 128 floats, +28 %)
+// is only taken when the padded shard still fits the feature share of the budget; otherwise the rows stay dense.
+// feat_budget_bytes <= 0: no budget known (capacity set by the caller, cache_memory == 0).
+int32_t legion_shard_pitch(int32_t F, int64_t rows, int64_t feat_budget_bytes)
+{
+    const int32_t aligned = legion_row_pitch(F);
+    if (aligned == F || feat_budget_bytes <= 0) return aligned;
+    return rows * aligned * (int64_t)sizeof(float) <= feat_budget_bytes ? aligned : F;
 }
 
 // FillUp, GPUCache.cu:769-826 (+ InitializeMap :306-323, Insert :325-371, FeatFillUp :200-205)
@@ -417,7 +470,12 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
     const int32_t V = noder->total_num_nodes;
     const int32_t F = noder->float_attr_len;
     const int Kg = c->Kg;
-    const int32_t pitch = legion_row_pitch(F);   // shard rows start on a 128-byte line (F = 100 -> 512-byte rows)
+    // shard rows start on a 128-byte line (F = 100 -> 512-byte rows) when that fits the feature share of EVERY clique's budget
+    int32_t pitch = legion_row_pitch(F);
+    for (int i = 0; i < c->Kc && pitch != F; i++) {
+        const double a = (i < (int)c->alpha.size() && c->alpha[i] >= 0.0) ? c->alpha[i] : 0.0;
+        pitch = legion_shard_pitch(F, c->node_capacity[i], c->cache_memory > 0 ? (int64_t)((1.0 - a) * (double)c->cache_memory) : 0);
+    }
     c->shard_pitch = pitch;
     c->chunk_shift.assign(c->Kc, 30);
     c->nchunks.assign(c->Kc, 1);

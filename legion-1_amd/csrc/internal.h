@@ -199,6 +199,7 @@ void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t K
 // ends[q] = end offset of the last row that starts before (q+1) << edge_shift   (q < nch - 1)
 void launch_chunk_ends(hipStream_t s, const int64_t* frag_indptr, int32_t capacity, int32_t edge_shift, int32_t nch, int64_t* ends);
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr);
+void launch_topo_transactions(hipStream_t s, const int32_t* order, const uint64_t* hot, uint64_t* out, int32_t V, const int64_t* indptr);
 void launch_build_head(hipStream_t s, const int64_t* indptr, const int32_t* indices, int32_t V, int32_t head_shift, int32_t* head);
 void sort_by_hotness_desc(hipStream_t s, unsigned long long* keys, int32_t* ids, int32_t n);
 void inclusive_scan_u64(hipStream_t s, const uint64_t* in, uint64_t* out, int32_t n);

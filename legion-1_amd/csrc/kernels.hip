@@ -1002,6 +1002,23 @@ __global__ void k_edge_mem(const int32_t* order, uint64_t* edge_mem, int32_t V, 
         edge_mem[i] = (uint64_t)(sizeof(int64_t) + sizeof(int32_t) * (indptr[id + 1] - indptr[id]));
     }
 }
+// PCM-free input of the cost model: 64-byte read transactions of the pre-sampling epoch's adjacency
+// accesses, estimated from the edge hotness.  AT[t] = sampled edges of the rank-t row QT[t] (Kernels.cu:525: +1 per sampled
+// edge).  Every sampled edge reads the row's 8-byte offset and one neighbour id (Kernels.cu:392-409); in 64-byte units a
+// row of deg <= 14 ids has both in one line, a longer row needs a second one: weight = ceil((8 + 4 * min(deg, 16)) / 64),
+// the "min(deg, .)" of the survey's formula taken at the 16 ids one transaction holds.  Integer only, deterministic.
+__host__ __device__ inline uint64_t topo_transactions_of(uint64_t sampled_edges, int64_t deg)
+{
+    const int64_t ids = deg < 16 ? (deg < 0 ? 0 : deg) : 16;
+    return sampled_edges * (uint64_t)((8 + 4 * ids + 63) / 64);
+}
+__global__ void k_topo_transactions(const int32_t* order, const uint64_t* hot, uint64_t* out, int32_t V, const int64_t* indptr)
+{
+    for (int32_t i = threadIdx.x + blockDim.x * blockIdx.x; i < V; i += gridDim.x * blockDim.x) {
+        const int32_t id = order[i];
+        out[i] = topo_transactions_of(hot[i], indptr[id + 1] - indptr[id]);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // host side: launch wrappers
@@ -1324,6 +1341,11 @@ void launch_build_head(hipStream_t s, const int64_t* indptr, const int32_t* indi
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)
 {
     k_edge_mem<<<grid_for(V, 256), 256, 0, s>>>(order, edge_mem, V, indptr);
+    HIP_CHECK_LAST();
+}
+void launch_topo_transactions(hipStream_t s, const int32_t* order, const uint64_t* hot, uint64_t* out, int32_t V, const int64_t* indptr)
+{
+    k_topo_transactions<<<grid_for(V, 256), 256, 0, s>>>(order, hot, out, V, indptr);
     HIP_CHECK_LAST();
 }
 

@@ -188,6 +188,8 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         (void)hipDeviceSynchronize();
         int32_t* nc = IPCEnv_GetNodeCounter(env, r->local_dev_id, r->current_pipe);
         if (nc) (void)hipMemset(nc, 0xFF, 16 * sizeof(int32_t));
+        int32_t* ec = IPCEnv_GetEdgeCounter(env, r->local_dev_id, r->current_pipe);   // no stale edge counts of the pipe's previous batch
+        if (ec) (void)hipMemset(ec, 0, 16 * sizeof(int32_t));
         (void)hipGetLastError();
         IPCEnv_IPCPost(env, r->local_dev_id, r->current_pipe);
         r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;

@@ -409,6 +409,14 @@ void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
     n->partition_count = P;
     n->total_num_nodes = info->total_num_nodes;
     n->float_attr_len = info->float_attr_len;
+    // float_attr_pitch is an extension field behind the reference's BuildInfo: 0 = dense.  Anything else must describe a
+    // layout the gather can read: at least F floats, and -- when F allows 16-byte chunks -- rows that stay 16-byte aligned
+    // (the float4 path is chosen from F and the base pointers).  A caller built against the shorter struct must zero it.
+    if (info->float_attr_pitch != 0 && (info->float_attr_pitch < info->float_attr_len ||
+                                        (info->float_attr_len % 4 == 0 && info->float_attr_pitch % 4 != 0))) {
+        LEGION_ARG_ERROR("GPUNodeStorage_Build: float_attr_pitch must be 0 (dense) or >= float_attr_len, and a multiple of 4 floats when float_attr_len is");
+        return;
+    }
     n->float_attr_pitch = info->float_attr_pitch > info->float_attr_len ? info->float_attr_pitch : info->float_attr_len;
     n->replica_pitch = 0;
     n->features_location = info->features_location;

@@ -42,6 +42,8 @@ std::vector<torch::Tensor> get_next(int feature_dim)
     require_env();
     legion_ipc_client_wait(env); // env->Wait(), ipc_service.cpp:42
     legion_ipc_client_read_counters(env, h_node_counter, h_edge_counter);
+    // a server that failed mid-batch posts the pipe with every node-counter word at -1 (runner.cpp, post_poisoned)
+    TORCH_CHECK(h_node_counter[0] >= 0, "ipc_service: the sampling server failed (poisoned batch posted)");
     const int dev = GetGPUDevice();
     const auto device = torch::Device(torch::kCUDA, dev);
     const auto i32 = torch::TensorOptions().dtype(torch::kI32).device(device);

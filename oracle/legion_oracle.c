@@ -406,7 +406,22 @@ void lo_cost_model(
 {
     const int max_payload_size = 64;                     /* CLS */
     int64_t memory_step = (int64_t)((double)(cache_memory * Kg) * 0.01); /* MIN_INTERVAL, :674 */
-    uint64_t total_trans_of_topo = counters[0] + counters[1];
+    uint64_t total_trans_of_topo = 0;
+    if (counters) {
+        total_trans_of_topo = counters[0] + counters[1];  /* the two Intel-PCM PCIe read counters, :675, Server.cu:100,108 */
+    } else {
+        /* No PCM here (Intel-only MSRs): the product estimates the epoch's adjacency transactions from its own hotness
+         * counters (sum over rows of edge_access_time * (8 + 4 * min(deg, .)) / 64).  Restated
+         * independently: a sampled edge reads the row's 8-byte offset and one neighbour id; rows whose offset + ids fit
+         * one 64-byte line (deg <= 14) cost one transaction per sampled edge, longer rows two ("." = the 16 ids of a line).
+         * Not reference arithmetic -- the reference always has the counters; parity of this branch is product-vs-oracle only. */
+        for (int32_t i = 0; i < V; i++) {
+            int64_t deg = csr_index[QT[i] + 1] - csr_index[QT[i]];
+            int64_t ids = deg > 16 ? 16 : (deg < 0 ? 0 : deg);
+            int64_t bytes = 8 + 4 * ids;
+            total_trans_of_topo += AT[i] * (uint64_t)((bytes + 63) / 64);
+        }
+    }
     uint64_t total_trans_of_feat = 0;
     for (int j = 0; j < Kg; j++)
         total_trans_of_feat += (uint64_t)(((int64_t)max_ids[j] * train_step * float_attr_len * (int64_t)sizeof(float)) / max_payload_size);

@@ -243,7 +243,7 @@ def cost_model(AF, AT, QT, indptr, V, F, cache_memory, Kg, counters, max_ids_lis
     AT = np.ascontiguousarray(AT, dtype=np.uint64)
     QT = np.ascontiguousarray(QT, dtype=np.int32)
     indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-    counters = np.ascontiguousarray(counters, dtype=np.uint64)
+    counters = None if counters is None else np.ascontiguousarray(counters, dtype=np.uint64)   # None: the PCM-free estimate
     mi = np.ascontiguousarray(max_ids_list, dtype=np.int32)
     nc_, ec_, a = C.c_int32(), C.c_int32(), C.c_int32()
     bt = C.c_float()

@@ -120,15 +120,18 @@ def test_a_leg_that_hangs_prints_the_headline_names_the_leg_and_exits_3():
     code = ("import sys, json, time; sys.path.insert(0, %r)\n"
             "import bench, legion1_amd.dist as D\n"
             "class _Ctx:\n"
-            "    rank, world, D = 0, 1, D\n"
+            "    rank, world, D = 0, %d, D\n"
             "line = {'metric': 'm', 'value': 42.0, 'legs_failed': [], 'extra_legs': {}}\n"
             "g = bench.LegGuard(_Ctx(), line)\n"
             "def stuck():\n"
             "    g.partial = {'value': 7.0}\n"
             "    time.sleep(60)\n"
             "g.run('unified_cache', 0.5, stuck)\n"
-            "print('never')\n") % ROOT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, cwd=ROOT)
+            "print('never')\n")
+    # N = 1 (the driver's BENCH run): nobody waits for this process and everything printed is valid -> the line, exit code 0
+    r1 = subprocess.run([sys.executable, "-c", code % (ROOT, 1)], capture_output=True, text=True, timeout=60, cwd=ROOT)
+    assert r1.returncode == 0 and "never" not in r1.stdout and '"hung": true' in r1.stdout
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, 2)], capture_output=True, text=True, timeout=60, cwd=ROOT)
     assert r.returncode == bench.LEG_HUNG_EXIT == 3 and "never" not in r.stdout
     import json
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -147,3 +150,66 @@ def test_parent_passes_the_hung_leg_exit_code_on():
     procs = [FakeProc([True], bench.LEG_HUNG_EXIT), FakeProc([True], 1)]
     rc, _ = _launch(procs, grace_s=0.0)
     assert rc == 1
+
+
+# ---- announcements of a caught PART of a leg are settled by that part's agreement collective ----------------------
+_GUARD_PRELUDE = ("import sys, json, time; sys.path.insert(0, %r)\n"
+                  "import bench\n"
+                  "class FakeD:\n"
+                  "    @staticmethod\n"
+                  "    def allgather_object(o, world): return [o] * world\n"
+                  "    @staticmethod\n"
+                  "    def barrier(world): pass\n"
+                  "class FakeStore:\n"
+                  "    def __init__(self): self.d = {}\n"
+                  "    def set(self, k, v): self.d[k] = v.encode() if isinstance(v, str) else v\n"
+                  "    def get(self, k): return self.d[k]\n"
+                  "    def check(self, ks): return all(k in self.d for k in ks)\n"
+                  "class _Ctx:\n"
+                  "    rank, world, D = 0, 2, FakeD\n"
+                  "bench.LegGuard.PEER_GRACE_S = 1.0\n"
+                  "line = {'metric': 'm', 'value': 42.0, 'legs_failed': [], 'extra_legs': {}}\n"
+                  "g = bench.LegGuard(_Ctx(), line)\n"
+                  "g.store = FakeStore()\n") % ROOT
+
+
+def _guard_script(body):
+    return subprocess.run([sys.executable, "-c", _GUARD_PRELUDE + body], capture_output=True, text=True, timeout=60, cwd=ROOT)
+
+
+def test_a_part_failure_every_rank_agreed_on_does_not_end_the_leg():
+    r = _guard_script("def leg():\n"
+                      "    g.store.set('legion_leg_failed/unified_cache/part', 'rank 1: exchange variant: boom')   # a peer's announcement\n"
+                      "    g.announce('exchange variant: boom')                                                     # and this rank's own\n"
+                      "    g.part_agreed()              # the agreement all-gather behind the part came back: every rank left it\n"
+                      "    time.sleep(3.0)              # the rest of the leg takes longer than the grace period\n"
+                      "    return {'value': 5.0}\n"
+                      "print('RES', g.run('unified_cache', 20.0, leg), line['legs_failed'])\n")
+    assert r.returncode == 0 and "RES {'value': 5.0} []" in r.stdout, (r.returncode, r.stdout, r.stderr[-1500:])
+
+
+def test_a_part_failure_a_rank_never_leaves_ends_the_run_once():
+    r = _guard_script("def leg():\n"
+                      "    g.store.set('legion_leg_failed/unified_cache/part', 'rank 1: exchange variant: boom')\n"
+                      "    time.sleep(30.0)             # this rank sits in the part's collectives: no agreement\n"
+                      "print('RES', g.run('unified_cache', 1.2, leg))\n")      # the plain timeout fires at about the same time
+    assert r.returncode == bench.LEG_HUNG_EXIT and "RES" not in r.stdout
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                          # timer and watcher race: printed ONCE
+    import json
+    f = json.loads(lines[0])["legs_failed"]
+    assert len(f) == 1 and f[0]["leg"] == "unified_cache" and f[0]["hung"] is True
+
+
+def test_a_rank_ignores_its_own_leg_level_announcement():
+    r = _guard_script("g.store.set('legion_leg_failed/lp', 'rank 0: something this rank said itself')\n"
+                      "def leg():\n"
+                      "    time.sleep(2.5)\n"
+                      "    return {'value': 1.0}\n"
+                      "print('RES', g.run('lp', 20.0, leg))\n")
+    assert r.returncode == 0 and "RES {'value': 1.0}" in r.stdout, (r.returncode, r.stdout, r.stderr[-1500:])
+    r = _guard_script("g.store.set('legion_leg_failed/lp', 'rank 1: a peer raised')\n"
+                      "def leg():\n"
+                      "    time.sleep(30.0)\n"
+                      "print('RES', g.run('lp', 20.0, leg))\n")
+    assert r.returncode == bench.LEG_HUNG_EXIT and "a peer raised" in r.stdout and "RES" not in r.stdout

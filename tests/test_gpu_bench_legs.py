@@ -13,10 +13,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(extra_env, *flags, timeout=400):
+def _bench(extra_env, *flags, timeout=400, gpus=2):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    env.update(LEGION_BENCH_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "4", "--warmup", "1",
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    if gpus > 1:
+        env.update(LEGION_BENCH_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--scale", "0.02", "--steps", "4", "--warmup", "1",
                         "--min-time", "0.05", "--extra-min-time", "0.05", "--presc-steps", "2"] + list(flags),
                        env=env, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -31,6 +33,8 @@ def test_two_rank_line_has_every_leg():
     assert u["Kg"] == 2 and u["value"] > 0 and min(u["rows_last_batch"][k] for k in ("own_shard", "peer_shards", "backing_table")) > 0
     x = u["exchange_variant"]
     assert x.get("error") is None and x["host_syncs_per_batch"] == 1.0 and x["allocations_in_timed_windows"] == 0
+    # two ranks on one device run the all-to-alls over gloo, staged through the host: labelled, and never printed as a result
+    assert x["staged_through_host"] is True and "value" not in x and x["rehearsal_ms_per_step_not_a_result"] > 0
     assert u["xgmi_read_GBps_per_gpu"] is None                       # two ranks on one device: not an xGMI number
     lp, uk = line["extra_legs"]["lp"], line["extra_legs"]["uk_union"]
     assert lp["value"] > 0 and lp["batch"] % 3 == 0 and uk["value"] > 0 and uk["Kg"] == 2 and uk["topo_rows_per_gpu"] > 0 and uk["F"] == 256
@@ -65,3 +69,38 @@ def test_a_leg_that_fails_on_one_rank_only_is_reported_within_seconds():
     f = line["legs_failed"][0]
     assert f["leg"] == "lp" and f["hung"] is True and "rank 1" in f["error"] and "injected failure" in f["error"]
     assert line["value"] > 0 and line["unified_cache"]["value"] > 0           # everything before the failed leg is in the line
+
+
+def test_one_gpu_line_has_every_single_gpu_baseline_path():
+    """the driver's N = 1 command carries every BASELINE path one GPU can measure, each as a guarded leg:
+    lp (config 5), cached_gather (config 3's FindFeat + gather), products_2hop (config 1, with its CPU legs), products_3hop (config 2),
+    partitioned_csr (config 4's sampler over CSR fragments).  Here at 2 % of the shapes; the driver runs the full ones."""
+    r, line = _bench({}, "--cpu-baseline-seconds", "1.5", "--measure-traffic", "off", gpus=1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert line["n_gpus"] == 1 and line["legs_failed"] == [] and line["value"] > 0 and line["cpu_baseline"]["value"] > 0
+    legs = line["extra_legs"]
+    assert list(legs) == ["lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]
+    for name, leg in legs.items():
+        assert leg.get("error") is None and leg["value"] > 0 and leg["ms_per_step"] > 0, (name, leg)
+        assert 0 < leg["gather_frac_of_hbm_peak"] < 1 and leg["sampler_us_per_batch"] > 0 and 0 < leg["pipeline_frac"] < 1, (name, leg)
+    assert legs["lp"]["batch"] % 3 == 0 and legs["lp"]["F"] == 128
+    cg = legs["cached_gather"]
+    assert cg["Kg"] == 1 and 0.2 < cg["cached_fraction_of_V"] < 0.3 and cg["F"] == 128
+    assert min(cg["rows_last_batch"][k] for k in ("own_shard", "backing_table")) > 0 and cg["rows_last_batch"]["peer_shards"] == 0
+    p2, p3 = legs["products_2hop"], legs["products_3hop"]
+    assert p2["fanout"] == [25, 10] and p3["fanout"] == [25, 10, 5] and p2["F"] == p3["F"] == 100
+    assert p2["cpu_baseline"]["value"] > 0 and p2["cpu_baseline"]["dgl_semantics"]["value"] > 0 and "cpu_baseline" not in p3
+    assert p3["value_overlap"] > 0 and p3["pipeline_frac_overlap"] > 0
+    pc = legs["partitioned_csr"]
+    assert pc["F"] == 256 and pc["fanout"] == [25, 10] and pc["topo_rows_per_gpu"] > 0 and pc["Kg"] == 1
+
+
+def test_a_symmetric_exchange_failure_does_not_cost_the_rest_of_the_line():
+    """the exchange variant failing on EVERY rank is a caught, reported part of the unified leg: the ranks agree
+    right behind it and go on together -- the in-kernel numbers and the extra legs survive, exit code 0 (round 3 ended every rank
+    with exit code 3 five seconds after the announcement)."""
+    r, line = _bench({"LEGION_BENCH_INJECT_ERROR": "exchange"})
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    u = line["unified_cache"]
+    assert "injected failure of the exchange variant" in u["exchange_variant"]["error"] and u["value"] > 0 and u["Kg"] == 2
+    assert line["legs_failed"] == [] and line["extra_legs"]["lp"]["value"] > 0 and line["extra_legs"]["uk_union"]["value"] > 0

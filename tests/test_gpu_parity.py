@@ -3,11 +3,13 @@ against the CPU oracle on the same seeded inputs -- bit exact for every id / ind
 for the (verbatim copied) f32 feature rows.  Run on the GPU box with `pytest -m gpu`."""
 import ctypes as C
 import os
+import sys
+import time
 
 import numpy as np
 import pytest
 
-from conftest import assert_batch_equal, load_golden, sha
+from conftest import ROOT, assert_batch_equal, load_golden, sha
 
 pytestmark = pytest.mark.gpu
 
@@ -405,12 +407,71 @@ def test_runner_posts_a_poisoned_pipe_when_an_operator_refuses(K, small_ds):
     L.legion_ipc_set_namespace(b"")
 
 
+def test_poisoned_pipe_reaches_the_trainer_as_an_error(K, small_ds, tmp_path):
+    """the only shipped consumer must act on the poisoned pipe.  A real `ipc_service` trainer process attaches to
+    an in-process runner; the runner's next batch fails (its feature buffer is taken away after the hand-shake), the pipe is
+    posted with nc[*] = -1 and zeroed edge counters, and the trainer's get_next raises "sampling server failed" instead of
+    building tensors with a negative dimension or the previous batch's edge counts."""
+    import subprocess
+    ds = small_ds
+    B, fan = 300, [10, 5]
+    L = K.lib()
+    ns = "lgn_t_poison2_%d_" % os.getpid()
+    L.legion_ipc_set_namespace(ns.encode())
+    eng = make_engine(K, ds, B, fan)
+    env = L.NewIPCEnv(1)
+    L.IPCEnv_Coordinate(env, C.byref(eng.info))
+    fan_arr = np.asarray(fan, dtype=np.int32)
+    rp = K.RunnerParams()
+    rp.device_id, rp.fanout, rp.hops = 0, fan_arr.ctypes.data, len(fan)
+    rp.cache, rp.graph, rp.noder, rp.env, rp.global_batch_id, rp.in_memory = eng.cache, eng.graph, eng.noder, env, 0, 1
+    runner = L.NewGPURunner()
+    L.Runner_Initialize(runner, C.byref(rp))
+    L.Runner_InitializeFeaturesBuffer(runner, C.byref(rp))
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    K.check()
+    log = open(str(tmp_path / "client.log"), "w+")
+    client = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_client_poison.py"), str(ds.spec.F)], stdout=log, stderr=subprocess.STDOUT,
+                              env=dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    try:
+        t0 = time.time()
+        while "ATTACHED" not in open(log.name).read():
+            assert client.poll() is None and time.time() - t0 < 240, open(log.name).read()[-3000:]
+            time.sleep(0.1)
+        # a good batch first: the pipe's edge counters now hold real counts a poisoned post must not leave behind
+        L.Runner_RunOnce(runner, C.byref(rp))
+        K.check()
+        pool = L.Runner_GetMemoryPool(runner)
+        for q in range(2):
+            L.GPUMemoryPool_SetFloatFeatures(pool, None, q)
+        rp.global_batch_id = 1
+        L.Runner_RunOnce(runner, C.byref(rp))      # fails: posts batch 0 (in flight) and then the poisoned pipe
+        assert b"feature buffer of the current pipe is not set" in (L.legion_last_error() or b"")
+        L.legion_clear_error()
+        ec = K.read_dev(L.IPCEnv_GetEdgeCounter(env, 0, 1), np.int32, 16)
+        assert (ec == 0).all(), ec
+        # the trainer consumes batch 0 (good) and raises on the poisoned pipe: exit code 0 only for exactly that
+        rc = client.wait(timeout=120)
+    except BaseException:
+        client.kill()
+        raise
+    text = open(log.name).read()
+    L.Runner_Delete(runner)
+    L.IPCEnv_Finalize(env)
+    eng.close()
+    L.legion_ipc_set_namespace(b"")
+    assert rc == 0 and "RAISED after 1 good batches" in text and "sampling server failed" in text, text[-3000:]
+
+
 # ---------------------------------------------------------------------------------------------------
 # cache: pre-sampling, ranking, cost model, fill-up, unified cache with Kg logical GPUs on one device
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("G,mode,chunk_bytes", [(1, 0, None), (2, 1, None), (4, 2, 65536), (4, 1, 40000), (8, 3, None), (8, 2, 50000)])
-def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, monkeypatch):
+@pytest.mark.parametrize("G,mode,chunk_bytes,pcm", [(1, 0, None, True), (2, 1, None, True), (4, 2, 65536, True), (4, 1, 40000, True), (8, 3, None, True),
+                                                      (8, 2, 50000, True), (1, 0, None, False), (4, 1, None, False)])
+def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, pcm, monkeypatch):
     # chunk_bytes: force the cache shards to be split into several chunk allocations (default chunk: 1 GiB)
+    # pcm=False: CostModel without the two Intel-PCM counters (what the `legion` server binary does: runner.cpp passes NULL) --
+    # the PCM-free transaction estimate of SURVEY section 5, computed on the device from AT / QT / indptr, against the oracle's
     if chunk_bytes is not None:
         monkeypatch.setenv("LEGION_SHARD_CHUNK_BYTES", str(chunk_bytes))
     else:
@@ -422,7 +483,7 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
     Kg = {0: 1, 1: 2, 2: 4, 3: 8}[mode]
     parts = oracle.split_seeds(ds.train, G)
     steps = min((len(p) - 1) // B for p in parts)
-    counters = [500000, 250000]               # stand-ins for the two Intel-PCM PCIe counters (Server.cu:100)
+    counters = [500000, 250000] if pcm else None   # stand-ins for the two Intel-PCM PCIe counters (Server.cu:100)
     budget = int(V * F * 4 * 0.15)
     eng = make_engine(K, ds, B, fan, G=G, cache_memory=budget, train_step=steps)
     orcs = [oracle.OracleRunner(ds.indptr, ds.indices, ds.features, V, F, B, fan, partition_count=G) for _ in range(G)]
@@ -479,8 +540,11 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, m
             j = m - Ki * Kg
             rpc, nch = L.GPUCache_ShardChunkRows(eng.cache, m), L.GPUCache_ShardChunkCount(eng.cache, m)
             assert nch == (cm["node_capacity"] + rpc - 1) // rpc and (nch > 1) == (chunk_bytes is not None)
-            pitch = L.GPUCache_ShardPitch(eng.cache)       # rows of a shard start on a 128-byte line (F = 100 -> 128 floats)
-            assert pitch == L.legion_row_pitch(F) and pitch >= F and (pitch * 4) % 128 == 0
+            # rows of a shard start on a 128-byte line (F = 100 -> 128 floats) only if the padded shard fits the feature share
+            # of the budget -- here (15 % of the table, planned in dense rows) it does not: cache_memory is a contract
+            pitch = L.GPUCache_ShardPitch(eng.cache)
+            assert pitch == L.legion_shard_pitch(F, cm["node_capacity"], int((1.0 - cm["alpha_idx"] * 0.01) * budget)) or G // Kg > 1
+            assert pitch in (F, L.legion_row_pitch(F)) and cm["node_capacity"] * pitch * 4 <= budget
             cache_rows = np.concatenate([K.read_dev(L.GPUCache_GetShardChunk(eng.cache, m, q), np.float32,
                                                     min(rpc, cm["node_capacity"] - q * rpc) * pitch).reshape(-1, pitch)[:, :F] for q in range(nch)])
             n_valid = len(range(j, min(V, cm["node_capacity"] * Kg), Kg))

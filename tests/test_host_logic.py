@@ -234,3 +234,42 @@ def _client_open_without_listener(tmp_ns):
 
 def test_client_open_refuses_a_chunk_descriptor_without_listener():
     _client_open_without_listener("lgn_t_nolisten_%d_" % os.getpid())
+
+
+def test_shard_pitch_respects_the_cache_budget():
+    """the cost model plans the feature cache in DENSE rows (capacity = budget / (F * 4), GPUCache.cu:727),
+    so a shard may only take the line-aligned pitch (F = 100 -> 128 floats, +28 %) when the padded shard still fits the budget;
+    the cache_memory contract: node_capacity * pitch * 4 <= cache_memory."""
+    import legion1_amd.capi as K
+    L = K.lib()
+    assert L.legion_row_pitch(100) == 128 and L.legion_row_pitch(128) == 128 and L.legion_row_pitch(256) == 256
+    for F in (100, 36, 7, 52, 128, 256):
+        aligned = L.legion_row_pitch(F)
+        for cache_memory in (1 << 20, 3_000_000, 10 << 30):
+            cap = cache_memory // (F * 4)                     # what the reference's sweep hands out at alpha = 0
+            pitch = L.legion_shard_pitch(F, cap, cache_memory)
+            assert pitch in (F, aligned) and cap * pitch * 4 <= cache_memory
+            assert pitch == (aligned if cap * aligned * 4 <= cache_memory else F)
+            assert L.legion_shard_pitch(F, cache_memory // (aligned * 4), cache_memory) == aligned   # fewer rows: the padded shard fits
+        assert L.legion_shard_pitch(F, 1 << 20, 0) == aligned                # no budget known: the caller set the capacity
+    assert L.legion_shard_pitch(100, 1000, 1000 * 400) == 100 and L.legion_shard_pitch(100, 1000, 1000 * 512) == 128
+
+
+def test_cost_model_without_pcm_counters(oracle, synth):
+    """counters=None: the PCM-free transaction estimate: sum over the ranked rows of
+    edge hotness x ceil((8 + 4 * min(deg, 16)) / 64).  Equals the explicit-counter model fed with that sum."""
+    spec = synth.spec_for("products", scale=0.002)
+    ds = synth.generate(spec, with_features=False)
+    V = spec.V
+    rng = np.random.RandomState(11)
+    AF, QF = oracle.candidate_selection([rng.zipf(1.6, V).astype(np.uint64) % 50], V)
+    AT, QT = oracle.candidate_selection([rng.zipf(1.5, V).astype(np.uint64) % 40], V)
+    deg = np.diff(ds.indptr)[QT]
+    w = (8 + 4 * np.minimum(deg, 16) + 63) // 64
+    assert set(np.unique(w)) <= {1, 2} and (w[deg <= 14] == 1).all() and (w[deg >= 15] == 2).all()
+    est = int((AT.astype(np.int64) * w).sum())
+    assert int(AT.sum()) < est <= 2 * int(AT.sum())
+    for budget in (200_000, 1_000_000, 3_000_000):
+        a = oracle.cost_model(AF, AT, QT, ds.indptr, V, spec.F, budget, 1, None, [5000], 24)
+        b = oracle.cost_model(AF, AT, QT, ds.indptr, V, spec.F, budget, 1, [est, 0], [5000], 24)
+        assert a == b

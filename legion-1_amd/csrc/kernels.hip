@@ -43,6 +43,7 @@
 #include "internal.h"
 #include <hipcub/hipcub.hpp>
 #include <mutex>
+#include <cstring>
 
 namespace legion {
 
@@ -329,7 +330,8 @@ constexpr int32_t kWinBase = 0x40000000;
 // k_write keeps <= 26 KB of tile prefix in LDS: one entry per tile up to 6.3 M slots per hop, per 2 tiles up to 12.6 M, ...
 // Swept on MI355X (profiles/r02_write_lds_sweep.md): 12288 entries (one per tile at the 10 M-slot bound of a {25,10,5} hop 3,
 // 42 KB, 3 workgroups per CU) 19.7 us avg / 108 us at the products shape; 6144 (pairs of tiles, 22 KB, 6 per CU) 17.9 / 91; 3072: 18.6; 1536: 19.0 / 116
-constexpr int kWriteEntries = 6144; // loser states are -2 - slot with slot < 2^30; winners sit below them
+constexpr int kWriteEntries = 6144;
+constexpr int kGatherLookupDefault = 0; // cached gather: 0 = lookup pass (k_row_ptrs), U > 0 = k_gather_lookup<U>; see launch_gather // loser states are -2 - slot with slot < 2^30; winners sit below them
 __device__ inline int32_t enc_win(int32_t r) { return -2 - (kWinBase + r); }
 __device__ inline bool is_win(int32_t v) { return v <= -2 - kWinBase; }
 __device__ inline int32_t win_rank(int32_t v) { return -2 - v - kWinBase; }
@@ -750,6 +752,81 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
                 if (NT >= 1) __builtin_nontemporal_store(val[u], reinterpret_cast<VT*>(g.dst) + dsti[u]);
                 else reinterpret_cast<VT*>(g.dst)[dsti[u]] = val[u];
             }
+    }
+}
+
+// FindFeat inside the gather, ONE probe per row and wave: the first lane a wave gives to a row resolves
+// id -> cache slot -> (clique GPU, chunk, row) -> source address (GPUCache.cu:387-400, Kernels.cu:672-691) and hands the address to
+// the row's other lanes by __shfl -- F = 128: two probes per wave instead of 64 (round 1 probed in every chunk lane: 426 us), no
+// row_ptr round trip through memory, no second launch.  The probe chain (id, map, chunk table) sits in front of the row loads of
+// the wave, so U work items per lane are resolved together: U chains overlap instead of following each other.
+template <typename VT, int U>
+__global__ __launch_bounds__(kBlock) void k_gather_lookup(GatherKArgs a)
+{
+    constexpr int VEC = sizeof(VT) / 4;
+    const GatherArgs& g = a.g;
+    const int32_t off = g.off_idx < 0 ? 0 : g.nc[g.off_idx];
+    const int32_t rows = g.nc[g.size_idx];
+    const int32_t C = g.F / VEC;
+    const int64_t total = (int64_t)rows * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tpitch = g.table_pitch > 0 ? g.table_pitch : g.F, spitch = g.shard_pitch > 0 ? g.shard_pitch : g.F;
+    const int lane = lane_id();
+    if (g.rows_seen && blockIdx.x == 0 && threadIdx.x == 0) *g.rows_seen = rows;
+    int32_t hits = 0;
+    for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 - lane < total; q0 += stride * U) {   // whole waves stay in the loop: shuffles below
+        uint32_t r[U], ch[U];
+        int32_t id[U], gidx[U];
+        bool lead[U], live[U];
+        int src_lane[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t q = q0 + u * stride;
+            live[u] = q < total;
+            r[u] = fdiv((uint32_t)(live[u] ? q : 0), a.div_c);           // rows * C < 2^31 is checked by the launcher
+            ch[u] = (uint32_t)(live[u] ? q : 0) - r[u] * (uint32_t)C;
+            // first lane of this wave that works on row r: the row's chunk 0 if it sits in this wave, else lane 0
+            const int64_t first = (int64_t)r[u] * C - (q - lane);
+            src_lane[u] = first > 0 ? (int)first : 0;
+            lead[u] = live[u] && lane == src_lane[u];
+            id[u] = lead[u] ? g.sampled_ids[off + (int32_t)r[u]] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) gidx[u] = (lead[u] && id[u] >= 0) ? g.feat_map[id[u]] : -1;
+        const VT* src[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float* p = nullptr;
+            if (lead[u]) {
+                if (gidx[u] >= 0) {
+                    const uint32_t didx = fdiv((uint32_t)gidx[u], a.div_cap);
+                    const uint32_t fidx = (uint32_t)gidx[u] - didx * (uint32_t)g.cache_capacity;
+                    const float* chunk = g.shard_tab[didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
+                    p = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * spitch;
+                    hits++;
+                } else if (id[u] >= 0 && g.table) {
+                    p = g.table + (int64_t)(id[u] % g.total_num_nodes) * tpitch;
+                }
+            }
+            const unsigned long long bits = (unsigned long long)(uintptr_t)p;
+            const uint32_t lo = __shfl((uint32_t)bits, src_lane[u]), hi = __shfl((uint32_t)(bits >> 32), src_lane[u]);
+            const float* rp = (const float*)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+            src[u] = (live[u] && rp && !(g.dst_rows > 0 && off + (int32_t)r[u] >= g.dst_rows)) ? reinterpret_cast<const VT*>(rp) + ch[u] : nullptr;
+        }
+        VT val[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (src[u]) val[u] = __builtin_nontemporal_load(src[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (src[u]) __builtin_nontemporal_store(val[u], reinterpret_cast<VT*>(g.dst) + ((int64_t)(off + (int32_t)r[u]) * g.F) / VEC + ch[u]);
+    }
+    if (g.hit_stats) { // feature_cache_hit (GPUCache.cu:130-147).  A row that straddles two waves is probed by both: count it once
+        // (by the wave that holds its chunk 0) -- hits were only added by leaders, so drop the lane-0 stand-ins
+        // [kept simple: the statistic is sampled every 500th batch; the launcher uses the lookup PASS for sampled batches]
+        for (int o = 32; o > 0; o >>= 1) hits += __shfl_down(hits, o);
+        if (lane == 0 && hits) atomicAdd(g.hit_stats, hits);
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(g.hit_stats + 1, rows);
     }
 }
 
@@ -1190,10 +1267,21 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // bound is typically filled 15-60 %, so the grid is sized from the row count an earlier launch of this kind
     // reported (rows_seen, no host round trip), + 25 %; without a report: the bound, at most 512 workgroups per CU.
     int grid;
+    // cached configurations: FindFeat + source selection.  $LEGION_GATHER_LOOKUP = pass (k_row_ptrs in front of the gather) |
+    // fused[1|2|4] (k_gather_lookup: one probe per row and wave inside the gather, U work items per lane).  A batch whose hit rate
+    // is sampled (every 500th) takes the pass: it counts every row exactly once.
+    int fused_u = 0;
     if (g.row_ptr && !g.row_ptr_ready) {
-        const int64_t est_rows = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
-        k_row_ptrs<<<grid_for(est_rows, kBlock * 4, 64), kBlock, 0, s>>>(a);
-        HIP_CHECK_LAST();
+        const char* e = getenv("LEGION_GATHER_LOOKUP");      // read per launch (a getenv is ~50 ns): tests switch it inside one process
+        int lookup_mode = kGatherLookupDefault;
+        if (e && !strncmp(e, "pass", 4)) lookup_mode = 0;
+        else if (e && !strncmp(e, "fused", 5)) lookup_mode = e[5] ? atoi(e + 5) : 2;
+        fused_u = (lookup_mode > 0 && !g.hit_stats && !g.table_on_host && a.lpr_shift < 0) ? lookup_mode : 0;
+        if (!fused_u) {
+            const int64_t est_rows = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
+            k_row_ptrs<<<grid_for(est_rows, kBlock * 4, 64), kBlock, 0, s>>>(a);
+            HIP_CHECK_LAST();
+        }
     }
     if (g.rows_hint > 0) {
         // (re-swept in round 2, profiles/r02_gather_grid_sweep.md: 1-4 iterations per lane and a 3-25 % margin all land
@@ -1203,7 +1291,12 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     } else {
         grid = grid_for((int64_t)rows_bound * lanes, kBlock, 512);
     }
-    if (vec4) k_gather<v4f, 1, 2><<<grid, kBlock, 0, s>>>(a);
+    if (fused_u) {
+        if (fused_u >= 4) { if (vec4) k_gather_lookup<v4f, 4><<<grid, kBlock, 0, s>>>(a); else k_gather_lookup<float, 4><<<grid, kBlock, 0, s>>>(a); }
+        else if (fused_u >= 2) { if (vec4) k_gather_lookup<v4f, 2><<<grid, kBlock, 0, s>>>(a); else k_gather_lookup<float, 2><<<grid, kBlock, 0, s>>>(a); }
+        else { if (vec4) k_gather_lookup<v4f, 1><<<grid, kBlock, 0, s>>>(a); else k_gather_lookup<float, 1><<<grid, kBlock, 0, s>>>(a); }
+    }
+    else if (vec4) k_gather<v4f, 1, 2><<<grid, kBlock, 0, s>>>(a);
     else k_gather<float, 1, 2><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
 }

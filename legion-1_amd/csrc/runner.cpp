@@ -32,6 +32,7 @@ struct Runner {
     int32_t feature_rows = 0;
     // $LEGION_BATCH_GRAPH=1: RunOnce replays one recorded hipGraph per (pipe, mode) instead of launching the ops
     bool use_graph = false;
+    int graph_mode = 0;             // $LEGION_BATCH_GRAPH: 1 one-stream graph, 2 fork/join graph, 3 sampler graph + gather launched on stream 1
     // Software pipelining of RunOnce (default; $LEGION_RUNNER_PIPELINE=0 = the reference's synchronous loop): the
     // host enqueues batch i and only then waits for batch i-1 and posts its pipe, so the sampler of batch i
     // (stream 0) overlaps the gathers of batch i-1 (stream 1) on the GPU.
@@ -77,7 +78,7 @@ void Runner_Initialize(Runner* r, RunnerParams* params)
     r->op_factory[r->op_num - 1] = NewCacheUpdater(r->op_num - 1);
 
     r->pipeline_depth = LEGION_PIPELINE_DEPTH;
-    { const char* e = getenv("LEGION_BATCH_GRAPH"); r->use_graph = e && atoi(e) != 0; }
+    { const char* e = getenv("LEGION_BATCH_GRAPH"); r->graph_mode = e ? atoi(e) : 0; r->use_graph = r->graph_mode != 0; }
     { const char* e = getenv("LEGION_RUNNER_PIPELINE"); r->pipelined = !(e && atoi(e) == 0); }
     for (auto& ev : r->done_ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int total_num_nodes = GPUNodeStorage_TotalNodeNum(noder);
@@ -206,14 +207,24 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         LegionBatchGraph*& g = r->graphs[r->current_pipe][r->mode];
         if (!g) { // record this (pipe, mode) once
             if (GPUMemoryPool_BeginBatchCapture(r->memorypool, r->streams[0]) == 0) {
-                // recorded on ONE stream: a fork/join graph (gathers on stream 1) replays ~0.1 ms slower per batch
-                // than the plain launches on this runtime (examples/serve_bench.py), a linear one does not
-                for (int i = 0; i < r->op_num; i++) {
-                    OpParams op = *r->op_params[i];
-                    op.stream = r->streams[0];
-                    op.event = nullptr;
-                    op.is_presc = 0;
-                    Operator_run(r->op_factory[i], &op);
+                if (r->graph_mode == 2) {
+                    // the two-stream op loop as recorded -- stream 1 joins the capture through the op events and is joined back
+                    // before the capture ends (profiles/r04_graph_trace.md has the comparison)
+                    run_ops();
+                    HIP_CHECK(hipEventRecord(r->events[r->op_num - 1], r->streams[1]));
+                    HIP_CHECK(hipStreamWaitEvent(r->streams[0], r->events[r->op_num - 1], 0));
+                } else {
+                    // recorded on ONE stream.  Mode 3 records the sampler side only (BatchGen, samplers, planner: the even ops);
+                    // the rows are gathered by one plain launch on stream 1 behind the graph, so the gather of batch i overlaps
+                    // the recorded sampler of batch i + 1 (the other pipe) -- what a single graph per batch cannot do
+                    for (int i = 0; i < r->op_num; i++) {
+                        if (r->graph_mode == 3 && (i & 1)) continue;
+                        OpParams op = *r->op_params[i];
+                        op.stream = r->streams[0];
+                        op.event = nullptr;
+                        op.is_presc = 0;
+                        Operator_run(r->op_factory[i], &op);
+                    }
                 }
                 g = GPUMemoryPool_EndBatchCapture(r->memorypool, r->streams[0]);
             }
@@ -225,8 +236,17 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
             }
         }
         LegionBatchGraph_Launch(g, r->streams[0], IPCEnv_GetLocalBatchId(env, batch_id));
-        if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[0]));
-        else HIP_CHECK(hipStreamSynchronize(r->streams[0]));
+        hipStream_t last = r->streams[0];
+        if (r->graph_mode == 3) {
+            HIP_CHECK(hipEventRecord(r->events[0], r->streams[0]));
+            HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[0], 0));
+            OpParams* fp = r->op_params[1];
+            get_feature_kernel_all(r->streams[1], (GPUCache*)fp->cache, (GPUNodeStorage*)fp->noder, r->memorypool, fp->device_id, fp->in_memory);
+            Operator_run(r->op_factory[r->op_num - 1], r->op_params[r->op_num - 1]);   // Updater, stream 1
+            last = r->streams[1];
+        }
+        if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], last));
+        else HIP_CHECK(hipStreamSynchronize(last));
     } else {
         run_ops();
         // the updater (last op, stream 1) is ordered behind every op of the batch through the op events

@@ -32,7 +32,8 @@ def _wait_ready(proc, log_path, timeout=240):
 
 @pytest.mark.parametrize("fan,budget_frac,tables,graph", [([25, 10], 0.2, "host", "0"), ([5, 4, 3], 10.0, "auto", "0"),
                                                          ([10, 5], 0.1, "device", "0"), ([25, 10], 0.2, "host", "1"),
-                                                         ([5, 4, 3], 10.0, "auto", "1")])
+                                                         ([5, 4, 3], 10.0, "auto", "1"), ([25, 10], 0.2, "host", "2"),
+                                                         ([5, 4, 3], 10.0, "auto", "3"), ([10, 5], 0.1, "device", "3")])
 def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac, tables, graph):
     assert os.path.exists(SERVER), "build the server: make -C legion-1_amd/csrc legion"
     spec = synth.spec_for("products", scale=0.004)
@@ -46,7 +47,8 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
         f.write(synth.meta_config_line(ds, data, B, budget, epochs, 0))
     ns = "t%d_%d_" % (os.getpid(), len(fan))
     # LEGION_TABLES: host = the reference's pinned-host tables read over PCIe, device/auto = replicated into HBM
-    # LEGION_BATCH_GRAPH=1: the runner replays one recorded hipGraph per (pipe, mode) instead of launching the ops
+    # LEGION_BATCH_GRAPH=1: the runner replays one recorded hipGraph per (pipe, mode) instead of launching the ops; 2: the same as a
+    # fork/join graph (the two-stream loop as recorded); 3: the sampler side as a graph, one plain gather on stream 1 behind it
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_TABLES=tables, LEGION_BATCH_GRAPH=graph)
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:

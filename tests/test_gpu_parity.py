@@ -893,7 +893,8 @@ def test_randomised_differential(K, oracle, seed):
 def test_randomised_clique_cache_differential(K, oracle, seed, monkeypatch):
     """The cached path under random configurations (S5 / S6 / S8 / S9): random graph, feature width (odd, not a multiple of 4, not a
     whole number of 128-byte lines), hop count and fan-outs, clique size Kg in {1, 2, 4, 8} with one or two cliques, forced node / edge
-    capacities from 0 to "more than V", shard / fragment chunk sizes, head table on or off, in-kernel or bulk-copy peer gather --
+    capacities from 0 to "more than V", shard / fragment chunk sizes, head table on or off, in-kernel or bulk-copy peer gather, FindFeat
+    as a lookup pass or fused into the gather (one probe per row and wave, 1 / 2 / 4 work items per lane) --
     pre-sampling hotness, ranking, id -> slot maps and every steady-state batch of every GPU bit-identical to the oracle."""
     rng = np.random.RandomState(7000 + seed)
     L = K.lib()
@@ -918,7 +919,8 @@ def test_randomised_clique_cache_differential(K, oracle, seed, monkeypatch):
     B = int(rng.randint(8, min(len(p) for p in parts)))
     steps = max(1, min((len(p) - 1) // B for p in parts))
     for name, val in (("LEGION_SHARD_CHUNK_BYTES", rng.choice(["20000", "150000", None])), ("LEGION_HEAD_TABLE", rng.choice(["0", "auto"])),
-                      ("LEGION_PEER_GATHER", rng.choice(["exchange", None]))):
+                      ("LEGION_PEER_GATHER", rng.choice(["exchange", None])),
+                      ("LEGION_GATHER_LOOKUP", ["pass", "fused1", "fused2", "fused4"][seed % 4])):     # FindFeat as a pass / inside the gather
         if val is None:
             monkeypatch.delenv(name, raising=False)
         else:

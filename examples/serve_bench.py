@@ -4,7 +4,9 @@ drains every batch of the schedule through the C-ABI IPC client, for the three R
 
     LEGION_RUNNER_PIPELINE=0   the reference's loop: enqueue, wait for the batch, post (Server.cu:301-328)
     (default)                  enqueue batch i, then wait for batch i-1 and post it (sampler i || gathers i-1)
-    LEGION_BATCH_GRAPH=1       one recorded hipGraph per (pipe, mode)
+    LEGION_BATCH_GRAPH=1       one recorded hipGraph per (pipe, mode), one stream
+    LEGION_BATCH_GRAPH=2       the same as a fork/join graph (the two-stream op loop as recorded)
+    LEGION_BATCH_GRAPH=3       the sampler side as a graph, the rows gathered by one plain launch on stream 1 behind it
 
     python examples/serve_bench.py [--workload products --scale 0.3 --batch 8000 --fanout 25,10 --epochs 3]
 """
@@ -66,8 +68,10 @@ def main():
     with open(meta, "w") as f:
         f.write(S.meta_config_line(ds, data, a.batch, 1 << 40, a.epochs, 0))
     server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
-    for name, extra in (("reference loop", {"LEGION_RUNNER_PIPELINE": "0"}), ("pipelined", {}), ("hipGraph", {"LEGION_BATCH_GRAPH": "1"})):
-        ns = "sb%d_%s_" % (os.getpid(), name[:3])
+    for name, extra in (("reference loop", {"LEGION_RUNNER_PIPELINE": "0"}), ("pipelined", {}), ("hipGraph", {"LEGION_BATCH_GRAPH": "1"}),
+                        ("fork/join graph", {"LEGION_BATCH_GRAPH": "2"}), ("graph + gather", {"LEGION_BATCH_GRAPH": "3"}), ("pipelined", {}),
+                        ("graph + gather", {"LEGION_BATCH_GRAPH": "3"})):
+        ns = "sb%d_%s%s_" % (os.getpid(), name[:3], extra.get("LEGION_BATCH_GRAPH", ""))
         env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         log = open(os.path.join(tmp, "server_%s.log" % name[:3]), "w")
         proc = subprocess.Popen([server, "1", "0", a.fanout, meta], stdout=log, stderr=subprocess.STDOUT, env=env, cwd=tmp)

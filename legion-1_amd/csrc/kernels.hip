@@ -331,7 +331,9 @@ constexpr int32_t kWinBase = 0x40000000;
 // Swept on MI355X (profiles/r02_write_lds_sweep.md): 12288 entries (one per tile at the 10 M-slot bound of a {25,10,5} hop 3,
 // 42 KB, 3 workgroups per CU) 19.7 us avg / 108 us at the products shape; 6144 (pairs of tiles, 22 KB, 6 per CU) 17.9 / 91; 3072: 18.6; 1536: 19.0 / 116
 constexpr int kWriteEntries = 6144;
-constexpr int kGatherLookupDefault = 0; // cached gather: 0 = lookup pass (k_row_ptrs), U > 0 = k_gather_lookup<U>; see launch_gather // loser states are -2 - slot with slot < 2^30; winners sit below them
+// cached gather: 0 = lookup pass (k_row_ptrs), U > 0 = k_gather_lookup<U>.  Same box, papers100M shape, 25 % of the rows cached: pass 416-423 us,
+// U = 1: 455, U = 2: 412-414, U = 4: 418 (profiles/r04_cached_gather.md) -- the probes themselves (1.94 M random 4-byte reads of a 444 MB map) bound it
+constexpr int kGatherLookupDefault = 2; // loser states are -2 - slot with slot < 2^30; winners sit below them
 __device__ inline int32_t enc_win(int32_t r) { return -2 - (kWinBase + r); }
 __device__ inline bool is_win(int32_t v) { return v <= -2 - kWinBase; }
 __device__ inline int32_t win_rank(int32_t v) { return -2 - v - kWinBase; }
@@ -1176,7 +1178,11 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
 {
     if (count <= 0 || slots_bound <= 0) { LEGION_ARG_ERROR("GPU_Random_Sampling: empty hop"); return; }
     const int max_tiles = (slots_bound + kTile - 1) / kTile;
-    const int grid = grid_for(max_tiles, 1, 8);
+    // Workgroups per CU of the persistent tile loops.  The memory system is saturated by the scattered probes long before the CUs
+    // are full: 4 workgroups (16 waves) per CU beat 8 by 2-4 % on hop 3 at every shape and tie on the small hops; 3 lose on hop 2
+    // (same-box sweep, profiles/r04_sampler.md).  $LEGION_SAMPLE_WG_PER_CU overrides (1..8).
+    static const int wg_per_cu = [] { const char* e = getenv("LEGION_SAMPLE_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 4; }();
+    const int grid = grid_for(max_tiles, 1, wg_per_cu);
     if (!b.aux_prepared) { // the previous launch prepared the slot states for another fan-out (or there was none)
         k_fill_aux<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.nc, count, b.aux, b.aux_cap);
         HIP_CHECK_LAST();

@@ -37,7 +37,8 @@ def analyse(d, hops):
     starts = [i for i, k in enumerate(ks) if k[2] == "k_seed"]
     batches = [ks[a:b] for a, b in zip(starts, starts[1:])]
     common = collections.Counter(len(b) for b in batches).most_common(1)[0][0]
-    batches = [b for b in batches if len(b) == common][20:-5]
+    batches = [b for b in batches if len(b) == common]
+    batches = batches[min(20, len(batches) // 4):len(batches) - 2]
     period = [b2[0][0] - b1[0][0] for b1, b2 in zip(batches, batches[1:]) if b2[0][0] - b1[0][0] < 5e6]
     busy, idle, ovl, ksum = [], [], [], []
     for b in batches:
@@ -78,7 +79,7 @@ def main():
     ap.add_argument("--scale", type=float, default=0.3)
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10")
-    ap.add_argument("--epochs", type=int, default=6)
+    ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "graph_trace"))
     a = ap.parse_args()
     import dataclasses

@@ -28,7 +28,7 @@ bench = None
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, counter)
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-           "--steps", "10", "--warmup", "2", "--min-time", "0", "--headline-only", "--cpu-baseline-seconds", "0"] + extra
+           "--steps", "10", "--warmup", "2", "--min-time", "0", "--headline-only", "--cpu-baseline-seconds", "0", "--measure-traffic", "off"] + extra
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         sys.exit(r.stdout[-2000:] + r.stderr[-2000:])
@@ -63,4 +63,5 @@ doc = {
 }
 path = os.path.join(ROOT, "profiles", tag + "_pmc_hbm_traffic" + ("_" + suffix if suffix else "") + ".json")
 json.dump(doc, open(path, "w"), indent=1)
+json.dump(doc, open(os.path.join(out_dir, os.path.basename(path)), "w"), indent=1)   # gpurun_out/ travels back from the GPU box, profiles/ does not
 print(json.dumps(doc["k_gather"]), json.dumps(doc["sampler"]))

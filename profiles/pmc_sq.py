@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Where does k_sample's time go?  SQ counters per kernel and hop (papers100M shape), one rocprofv3 --pmc pass per counter group.
-   python3 profiles/pmc_sq.py > gpurun_out/<dir>/pmc_sq.log        (on the GPU box, from the repository root)"""
+"""Where does k_sample's time go?  SQ counters per kernel and hop, one rocprofv3 --pmc pass per counter group (no trace domains).
+   python3 profiles/pmc_sq.py [l2] [bench.py flags, e.g. --workload products --fanout 25,10,5] > gpurun_out/<dir>/pmc_sq.log
+   (on the GPU box, from the repository root; default: the papers100M headline shape.  `l2`: the L2 / memory-side request counters
+   -- TCC hits, misses, EA reads / writes / atomics -- instead of the SQ groups)"""
 import collections
 import csv
 import glob
@@ -13,12 +15,17 @@ GROUPS = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD",
           ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_ANY"],
           ["SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_INT32"],
           ["SQ_WAVES", "SQ_INST_CYCLES_VMEM_RD", "SQ_INST_CYCLES_VMEM_WR", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SMEM"]]
+ARGS = sys.argv[1:]
+if ARGS and ARGS[0] == "l2":
+    ARGS = ARGS[1:]
+    GROUPS = [["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"], ["TCC_EA0_ATOMIC_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"],
+              ["TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_TCC_ATOMIC_WITH_RET_REQ_sum"]]
 env = dict(os.environ, TMPDIR="/tmp")
 out = collections.defaultdict(dict)
 for gi, grp in enumerate(GROUPS):
     d = os.path.join(ROOT, "gpurun_out", "pmc_sq", "g%d" % gi)
     cmd = ["rocprofv3", "--pmc"] + grp + ["--output-format", "csv", "-d", d, "--", "python3", os.path.join(ROOT, "bench.py"),
-                                         "--steps", "6", "--warmup", "2", "--min-time", "0", "--headline-only", "--cpu-baseline-seconds", "0"] + sys.argv[1:]
+                                         "--steps", "6", "--warmup", "2", "--min-time", "0", "--headline-only", "--cpu-baseline-seconds", "0", "--measure-traffic", "off"] + ARGS
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     if r.returncode != 0:
         print("group", gi, "failed:", r.stderr[-800:])
@@ -47,6 +54,6 @@ for gi, grp in enumerate(GROUPS):
     for (key, c), v in acc.items():
         out[key][c] = sum(v) / len(v)
 names = [c for g in GROUPS for c in g]
-print("%-12s %3s " % ("kernel", "hop") + " ".join("%14s" % c.replace("SQ_", "")[:14] for c in names))
+print("%-12s %3s " % ("kernel", "hop") + " ".join("%14s" % c.replace("SQ_", "").replace("_sum", "")[-14:] for c in names))
 for key in sorted(out):
     print("%-12s %3d " % key + " ".join("%14.4g" % out[key].get(c, float("nan")) for c in names))

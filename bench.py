@@ -1072,6 +1072,7 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
     ranking + fill-up of the OWN shard (rank-t row on GPU t % N), then a HIP-IPC exchange of the shards."""
     H = len(fan)
     pool = eng.pools[me]
+    t_presc = time.time()
     for it in range(args.presc_steps):
         L.GPUMemoryPool_SetCurrentPipe(pool, 0)
         L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
@@ -1081,13 +1082,17 @@ def build_unified_cache(args, K, D, L, eng, me, world, V, F, B, fan, dev):
         L.make_update_plan(None, eng.graph, eng.cache, pool, me, K.TRAINMODE)
     L.d_stream_sync(None)
     K.check()
+    t_presc, t_build = time.time() - t_presc, time.time()
     D.allreduce_device_u64(K, L.GPUCache_GetNodeAccessedMap(eng.cache, me), V, world, device=dev)
     D.allreduce_device_u64(K, L.GPUCache_GetEdgeAccessedMap(eng.cache, me), V, world, device=dev)
     rows = int(V * args.cache_frac) // world + 1
     mode = {1: 0, 2: 1, 4: 2, 8: 3}[world]
     topo_rows = (int(V * args.topo_frac) // world + 1) if args.topo_frac > 0 else 0
     eng.build_cache(cache_agg_mode=mode, node_capacity=rows, edge_capacity=topo_rows, train_step=args.presc_steps)
+    L.d_stream_sync(None)
     info = {"Kg": world, "rows_per_gpu": rows, "cached_fraction_of_V": round(rows * world / V, 4), "presc_steps": args.presc_steps,
+            # one-off costs (S7 / S8 / S9): the pre-sampling epoch, then hotness all-reduce + ranking (two radix sorts of V keys) + maps + fill-up
+            "presc_s": round(t_presc, 3), "cache_build_s": round(time.time() - t_build, 3),
             "topology": "replicated (4-byte peer probes are latency bound; SURVEY 5)" if topo_rows == 0 else
                         f"hottest {topo_rows} adjacency rows per GPU in partitioned CSR fragments (owner/row lookup fused into the sampler), rest from the replica",
             "topo_rows_per_gpu": topo_rows}

@@ -775,7 +775,6 @@ __global__ __launch_bounds__(kBlock) void k_gather_lookup(GatherKArgs a)
     const int64_t tpitch = g.table_pitch > 0 ? g.table_pitch : g.F, spitch = g.shard_pitch > 0 ? g.shard_pitch : g.F;
     const int lane = lane_id();
     if (g.rows_seen && blockIdx.x == 0 && threadIdx.x == 0) *g.rows_seen = rows;
-    int32_t hits = 0;
     for (int64_t q0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q0 - lane < total; q0 += stride * U) {   // whole waves stay in the loop: shuffles below
         uint32_t r[U], ch[U];
         int32_t id[U], gidx[U];
@@ -805,7 +804,6 @@ __global__ __launch_bounds__(kBlock) void k_gather_lookup(GatherKArgs a)
                     const uint32_t fidx = (uint32_t)gidx[u] - didx * (uint32_t)g.cache_capacity;
                     const float* chunk = g.shard_tab[didx * (uint32_t)g.nchunks + (fidx >> g.chunk_shift)];
                     p = chunk + (int64_t)(fidx & ((1u << g.chunk_shift) - 1u)) * spitch;
-                    hits++;
                 } else if (id[u] >= 0 && g.table) {
                     p = g.table + (int64_t)(id[u] % g.total_num_nodes) * tpitch;
                 }
@@ -823,13 +821,8 @@ __global__ __launch_bounds__(kBlock) void k_gather_lookup(GatherKArgs a)
         for (int u = 0; u < U; u++)
             if (src[u]) __builtin_nontemporal_store(val[u], reinterpret_cast<VT*>(g.dst) + ((int64_t)(off + (int32_t)r[u]) * g.F) / VEC + ch[u]);
     }
-    if (g.hit_stats) { // feature_cache_hit (GPUCache.cu:130-147).  A row that straddles two waves is probed by both: count it once
-        // (by the wave that holds its chunk 0) -- hits were only added by leaders, so drop the lane-0 stand-ins
-        // [kept simple: the statistic is sampled every 500th batch; the launcher uses the lookup PASS for sampled batches]
-        for (int o = 32; o > 0; o >>= 1) hits += __shfl_down(hits, o);
-        if (lane == 0 && hits) atomicAdd(g.hit_stats, hits);
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(g.hit_stats + 1, rows);
-    }
+    // (feature_cache_hit, GPUCache.cu:130-147, is counted by the lookup PASS: the launcher sends every batch whose hit rate is
+    // sampled through k_row_ptrs, which sees each row exactly once -- here a row that straddles two waves is probed by both)
 }
 
 // ------------------------------------------------------------------------------------------------

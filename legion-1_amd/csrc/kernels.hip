@@ -165,6 +165,7 @@ struct SampleArgs {
     int32_t count;
     int32_t op_id;
     int32_t window;            // lanes to look back for a repeated draw of the same row: min(count - 1, 8)
+    int32_t prefilter_from_op; // first op_id whose claims are preceded by the pre-filter load (4: hop 2; hop 1 never)
 };
 
 template <bool PRESC, bool PARTITIONED>
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                     // nothing, profiles/r02_sampler_experiments.md)
                     // hop 1: nearly every neighbour is new, so the pre-filter load would only add a dependent round trip in front
                     // of the claim -- go straight to the atomic (it returns the exact entry either way)
-                    unsigned long long cur = (a.op_id == 2) ? ~0ull : a.pos_map[dst];
+                    unsigned long long cur = (a.op_id < a.prefilter_from_op) ? ~0ull : a.pos_map[dst];
                     if (cur > mine) {
                         const unsigned long long old = atomicMin(a.pos_map + dst, mine);
                         if (old > mine) {
@@ -1192,6 +1193,9 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     a.fdiv = FastDiv((uint32_t)count);
     a.count = count; a.op_id = op_id;
     a.window = std::min(count - 1, 8);
+    // hop 1 goes straight to the atomic (see k_sample); $LEGION_PREFILTER_FROM_HOP moves that boundary (experiment knob, profiles/r04_sampler.md)
+    static const int prefilter_from_hop = [] { const char* e = getenv("LEGION_PREFILTER_FROM_HOP"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 9 ? v : 2; }();
+    a.prefilter_from_op = 2 * prefilter_from_hop;
     const bool part = csr.topo_owner != nullptr;
     if (is_presc) k_sample<true, false><<<grid, kBlock, 0, s>>>(a);
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10")
     ap.add_argument("--epochs", type=int, default=20)
+    ap.add_argument("--variants", default="all", help="comma list of: reference loop,pipelined,hipGraph,fork/join graph,graph + gather")
     ap.add_argument("--full-eval", action="store_true", help="keep the full validation / test sets (512-seed batches)")
     a = ap.parse_args()
     if a.consume:
@@ -68,9 +69,12 @@ def main():
     with open(meta, "w") as f:
         f.write(S.meta_config_line(ds, data, a.batch, 1 << 40, a.epochs, 0))
     server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
-    for name, extra in (("reference loop", {"LEGION_RUNNER_PIPELINE": "0"}), ("pipelined", {}), ("hipGraph", {"LEGION_BATCH_GRAPH": "1"}),
-                        ("fork/join graph", {"LEGION_BATCH_GRAPH": "2"}), ("graph + gather", {"LEGION_BATCH_GRAPH": "3"}), ("pipelined", {}),
-                        ("graph + gather", {"LEGION_BATCH_GRAPH": "3"})):
+    variants = [("reference loop", {"LEGION_RUNNER_PIPELINE": "0"}), ("pipelined", {}), ("hipGraph", {"LEGION_BATCH_GRAPH": "1"}),
+                ("fork/join graph", {"LEGION_BATCH_GRAPH": "2"}), ("graph + gather", {"LEGION_BATCH_GRAPH": "3"}), ("pipelined", {}),
+                ("graph + gather", {"LEGION_BATCH_GRAPH": "3"})]
+    if a.variants != "all":
+        variants = [v for v in variants[:5] if v[0] in a.variants.split(",")]
+    for name, extra in variants:
         ns = "sb%d_%s%s_" % (os.getpid(), name[:3], extra.get("LEGION_BATCH_GRAPH", ""))
         env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         log = open(os.path.join(tmp, "server_%s.log" % name[:3]), "w")

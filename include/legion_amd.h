@@ -409,6 +409,14 @@ int32_t* IPCEnv_GetAggSrc(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int32_t* IPCEnv_GetAggDst(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int32_t* IPCEnv_GetNodeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int32_t* IPCEnv_GetEdgeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
+/* extension: the slab carries a host mirror of both counter arrays of every (device, pipe) behind the reference's struct, so that a
+ * trainer reads them without a device copy (the reference's blocking cudaMemcpy, ipc_cuda_kernel.cu:195-196, synchronises the trainer
+ * with its own queued GPU work once per batch).  IPCEnv_MirrorCounters queues the copy of the current batch's counters on `stream`
+ * (behind the kernels that wrote them; wait for that stream before posting); IPCEnv_IPCPost copies synchronously when it was not called;
+ * IPCEnv_SetMirror fills the mirror from the host (poisoned pipe). */
+void IPCEnv_MirrorCounters(IPCEnv* e, int32_t dev_id, int32_t current_pipe, void* stream);
+void IPCEnv_SetMirror(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t nc_fill, int32_t ec_fill);
+int IPCEnv_SlabPinned(IPCEnv* e);   /* 1: the slab is page-locked (hipHostRegister), IPCEnv_MirrorCounters queues real asynchronous copies */
 void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int IPCEnv_IPCTryWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t timeout_ms); /* 0 = acquired */
@@ -430,7 +438,8 @@ void legion_ipc_client_post(LegionIPCClient* c);              /* Post(), :103-10
 void* legion_ipc_client_buffer(LegionIPCClient* c, int32_t which);
 void legion_ipc_client_steps(LegionIPCClient* c, int32_t steps[3]);
 int32_t legion_ipc_client_hops(LegionIPCClient* c);
-/* copies both 16-int counters of the current pipe to the host (ipc_cuda_kernel.cu:195-196) */
+/* both 16-int counters of the current pipe (ipc_cuda_kernel.cu:195-196): from the server's host mirror when it maintains one, else by
+ * a blocking device copy like the reference */
 void legion_ipc_client_read_counters(LegionIPCClient* c, int32_t h_node_counter[16], int32_t h_edge_counter[16]);
 void legion_ipc_client_close(LegionIPCClient* c);             /* Finalize(), :141-156 */
 

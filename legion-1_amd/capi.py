@@ -181,6 +181,9 @@ _SIGS = {
     "NewCachePlanner": (vp, [C.c_int]), "NewCacheUpdater": (vp, [C.c_int]),
     "Operator_run": (None, [vp, vp]), "Operator_Delete": (None, [vp]),
     "NewIPCEnv": (vp, [i32]),
+    "IPCEnv_MirrorCounters": (None, [vp, i32, i32, vp]),
+    "IPCEnv_SetMirror": (None, [vp, i32, i32, i32, i32]),
+    "IPCEnv_SlabPinned": (C.c_int, [vp]),
     "IPCEnv_Coordinate": (None, [vp, vp]),
     "IPCEnv_GetMaxStep": (i32, [vp]),
     "IPCEnv_InitializeSamplesBuffer": (None, [vp, i32, i32, i32, i32, i32]),

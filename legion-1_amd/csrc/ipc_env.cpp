@@ -34,8 +34,15 @@ struct shmStruct {
     int32_t steps[3];
     hipIpcMemHandle_t memHandle[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH][LEGION_MEMORY_USAGE];
     int32_t ext_hops; // extension, outside the reference's 7180 bytes
+    // extension: host mirror of the two 16-int counter arrays of every (device, pipe), filled by the server before it posts the
+    // pipe.  The reference's trainer reads them with a blocking cudaMemcpy from the IPC device buffers (ipc_cuda_kernel.cu:195-196):
+    // on the legacy default stream that copy waits for everything the trainer has queued -- one implicit device synchronisation per
+    // batch.  A client that finds the magic set reads the mirror instead; the device buffers 5 / 6 stay valid for everybody else.
+    uint32_t ext_mirror_magic;
+    int32_t ext_counters[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH][32];   // nc[16] | ec[16]
 };
 static_assert(offsetof(shmStruct, ext_hops) == 12 + 8 * 2 * 7 * 64, "reference shm layout changed");
+static const uint32_t kMirrorMagic = 0x4C474E43u;   // "LGNC"
 
 static std::string g_namespace;
 static bool g_ns_init = false;
@@ -246,6 +253,8 @@ struct IPCEnv {
     std::vector<int32_t> train_batch_size, valid_batch_size, test_batch_size;
     int32_t train_step = 0, valid_step = 0, test_step = 0, epoch = 0, pipeline_depth = LEGION_PIPELINE_DEPTH;
     std::vector<VmmRegion*> vmm;   // feature buffers above the HIP-IPC size limit (chunked, mapped, served over a unix socket)
+    bool shm_pinned = false;       // the slab is registered with the runtime: asynchronous copies can target the counter mirror
+    bool mirror_fresh[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH] = {};   // IPCEnv_MirrorCounters ran for the batch about to be posted
 };
 
 extern "C" {
@@ -255,6 +264,8 @@ void legion_ipc_set_namespace(const char* ns)
     g_namespace = ns ? ns : "";
     g_ns_init = true;
 }
+
+static void pin_slab(IPCEnv* e);
 
 // ============================ server half ==============================================================
 // CUDAIPCEnv::CUDAIPCEnv, CUDA_IPC_Service.cu:41-65
@@ -279,7 +290,19 @@ IPCEnv* NewIPCEnv(int32_t device_count)
     rs(e->ids); rs(e->float_features); rs(e->labels); rs(e->agg_src); rs(e->agg_dst); rs(e->node_counter); rs(e->edge_counter);
     e->semr.assign(device_count, {});
     e->semw.assign(device_count, {});
+    pin_slab(e);
     return e;
+}
+
+// Page-lock the slab so that a copy engine can write the counter mirror (hipMemcpyAsync into pageable memory is staged and
+// synchronous).  Called with a device current; failure only costs the asynchronous path.
+static void pin_slab(IPCEnv* e)
+{
+    if (e->shm_pinned || !e->shm) return;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE), bytes = (sizeof(shmStruct) + page - 1) / page * page;
+    if (hipHostRegister((void*)e->shm, bytes, hipHostRegisterPortable) == hipSuccess) e->shm_pinned = true;
+    else (void)hipGetLastError();
+    e->shm->ext_mirror_magic = kMirrorMagic;    // the mirror is maintained either way (synchronously in IPCPost if need be)
 }
 
 // Coordinate, CUDA_IPC_Service.cu:66-134
@@ -434,7 +457,43 @@ ENV_GETTER(NodeCounter, node_counter, int32_t)
 ENV_GETTER(EdgeCounter, edge_counter, int32_t)
 #undef ENV_GETTER
 
-void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe) { sem_post(e->semw[dev_id][current_pipe]); }
+// Queue the copy of the pipe's counters into the host mirror on `stream`, behind the kernels that wrote them.  The caller posts the
+// pipe only after it has waited for that stream's work (the runner waits for an event recorded behind this call).
+void IPCEnv_MirrorCounters(IPCEnv* e, int32_t dev_id, int32_t current_pipe, void* stream)
+{
+    if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count || e->node_counter[dev_id].empty()) return;
+    const int q = current_pipe % e->pipeline_depth;
+    if (!e->shm_pinned) return;     // IPCPost copies synchronously instead
+    int32_t* m = (int32_t*)&e->shm->ext_counters[dev_id][q][0];
+    HIP_CHECK(hipMemcpyAsync(m, e->node_counter[dev_id][q], 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_CHECK(hipMemcpyAsync(m + 16, e->edge_counter[dev_id][q], 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    e->mirror_fresh[dev_id][q] = true;
+}
+int IPCEnv_SlabPinned(IPCEnv* e) { return e && e->shm_pinned ? 1 : 0; }
+// The mirror of a pipe whose counters the HOST decides (a poisoned pipe: nc[*] = -1, ec[*] = 0)
+void IPCEnv_SetMirror(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t nc_fill, int32_t ec_fill)
+{
+    if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count) return;
+    const int q = current_pipe % e->pipeline_depth;
+    for (int i = 0; i < 16; i++) { e->shm->ext_counters[dev_id][q][i] = nc_fill; e->shm->ext_counters[dev_id][q][16 + i] = ec_fill; }
+    e->mirror_fresh[dev_id][q] = true;
+}
+void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
+{
+    const int q = current_pipe % e->pipeline_depth;
+    if (e->shm && e->shm->ext_mirror_magic == kMirrorMagic && !e->mirror_fresh[dev_id][q] && !e->node_counter[dev_id].empty()) {
+        // a producer that did not queue the mirror copy (a reference-style RunOnce on this library): copy now -- the batch is
+        // complete when a pipe is posted, so a blocking copy is correct, merely slower than the queued one
+        DeviceGuard guard(dev_id);
+        int32_t h[32];
+        if (hipMemcpy(h, e->node_counter[dev_id][q], 64, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(h + 16, e->edge_counter[dev_id][q], 64, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int i = 0; i < 32; i++) e->shm->ext_counters[dev_id][q][i] = h[i];
+        else { (void)hipGetLastError(); e->shm->ext_mirror_magic = 0; }   // clients fall back to the device buffers
+    }
+    e->mirror_fresh[dev_id][q] = false;
+    sem_post(e->semw[dev_id][current_pipe]);
+}
 void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
 {
     while (sem_wait(e->semr[dev_id][current_pipe]) != 0 && errno == EINTR) {}
@@ -480,6 +539,7 @@ void IPCEnv_Finalize(IPCEnv* e)
     for (VmmRegion* r : e->vmm) { DeviceGuard guard(r->device); vmm_release(r); }
     e->vmm.clear();
     if (e->shm) {
+        if (e->shm_pinned) { (void)hipHostUnregister((void*)e->shm); e->shm_pinned = false; }
         munmap((void*)e->shm, sizeof(shmStruct));
         close(e->shm_fd);
         shm_unlink(shm_name().c_str());
@@ -633,6 +693,12 @@ void legion_ipc_client_steps(LegionIPCClient* c, int32_t steps[3])
 int32_t legion_ipc_client_hops(LegionIPCClient* c) { return c->hops; }
 void legion_ipc_client_read_counters(LegionIPCClient* c, int32_t h_node_counter[16], int32_t h_edge_counter[16])
 {
+    if (c->shm->ext_mirror_magic == kMirrorMagic) {
+        // the server's host mirror of this pipe: no device copy, no implicit synchronisation with the trainer's own GPU work
+        const volatile int32_t* m = &c->shm->ext_counters[c->device][c->current_pipe][0];
+        for (int i = 0; i < 16; i++) { h_node_counter[i] = m[i]; h_edge_counter[i] = m[16 + i]; }
+        return;
+    }
     HIP_CHECK(hipMemcpy(h_node_counter, c->buf[c->current_pipe][5], 16 * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_CHECK(hipMemcpy(h_edge_counter, c->buf[c->current_pipe][6], 16 * sizeof(int32_t), hipMemcpyDeviceToHost));
 }

@@ -191,6 +191,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         if (nc) (void)hipMemset(nc, 0xFF, 16 * sizeof(int32_t));
         int32_t* ec = IPCEnv_GetEdgeCounter(env, r->local_dev_id, r->current_pipe);   // no stale edge counts of the pipe's previous batch
         if (ec) (void)hipMemset(ec, 0, 16 * sizeof(int32_t));
+        IPCEnv_SetMirror(env, r->local_dev_id, r->current_pipe, -1, 0);
         (void)hipGetLastError();
         IPCEnv_IPCPost(env, r->local_dev_id, r->current_pipe);
         r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
@@ -245,13 +246,15 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
             Operator_run(r->op_factory[r->op_num - 1], r->op_params[r->op_num - 1]);   // Updater, stream 1
             last = r->streams[1];
         }
+        IPCEnv_MirrorCounters(env, r->local_dev_id, r->current_pipe, last);   // behind every kernel of the batch (the graph / the gather)
         if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], last));
         else HIP_CHECK(hipStreamSynchronize(last));
     } else {
         run_ops();
         // the updater (last op, stream 1) is ordered behind every op of the batch through the op events
+        IPCEnv_MirrorCounters(env, r->local_dev_id, r->current_pipe, r->streams[1]);
         if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[1]));
-        else HIP_CHECK(hipEventSynchronize(r->events[r->op_num - 1])); // reference: spin on cudaEventQuery
+        else HIP_CHECK(hipStreamSynchronize(r->streams[1])); // reference: spin on cudaEventQuery of the updater's event (Server.cu:318-324)
     }
     if (error_pending()) {
         // an operator refused its arguments (sticky error): the buffers of this pipe hold stale data.  Never hand

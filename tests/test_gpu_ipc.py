@@ -387,6 +387,32 @@ def test_three_gigabyte_feature_buffer_reaches_a_pytorch_process(tmp_path):
             server.kill()
 
 
+def test_counter_mirror_serves_every_kind_of_producer(tmp_path):
+    """The slab's host mirror of the counters (what `ipc_service.get_next` reads instead of the reference's blocking device copy): a producer
+    that only calls IPCEnv_IPCPost (a reference-style RunOnce), one that queues IPCEnv_MirrorCounters on its stream (the runner), and a
+    host-decided mirror (poisoned pipe) -- the client gets the right words each time, and the IPC device buffers 5 / 6 still hold the
+    counters for a trainer that reads them the reference's way."""
+    ns = "mir%d_" % os.getpid()
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    script = os.path.join(ROOT, "tests", "ipc_mirror.py")
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([sys.executable, script, "server"], env=env, stdout=lf, stderr=subprocess.STDOUT)
+    try:
+        t0 = time.time()
+        while "ready" not in open(log, errors="ignore").read():
+            assert server.poll() is None and time.time() - t0 < 120, open(log, errors="ignore").read()[-2000:]
+            time.sleep(0.2)
+        client = subprocess.run([sys.executable, script, "client"], env=env, capture_output=True, text=True, timeout=120)
+        assert client.returncode == 0 and client.stdout.count("mirror ok, device buffers ok") == 3, client.stdout[-2000:] + client.stderr[-2000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0 and "server: done" in open(log).read(), open(log).read()[-2000:]
+        assert "slab pinned = 1" in open(log).read()       # the queued copies are real asynchronous DMA into the slab on this runtime
+    finally:
+        if server.poll() is None:
+            server.kill()
+
+
 def test_client_open_refuses_a_chunk_descriptor_without_listener_gpu():
     """Same refusal as the CPU test, with a real device behind it: no mapping may survive (the reserve / import / map steps
     that ran are undone) and the process can still allocate afterwards.  Runs in a child: the trainer half is per process."""

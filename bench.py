@@ -549,6 +549,7 @@ def leg_summary(c, leg, what):
             # (sampler + gather algorithmic bytes) / time / (8 TB/s x N): the whole batch against the HBM roofline
             "pipeline_frac": round(leg["job_bytes"] / el / 1e9 / (HBM_PEAK_GBPS * c.world), 4),
             "value_overlap": alt.get("value"), "ms_per_step_overlap": alt.get("ms_per_step"), "pipeline_frac_overlap": alt.get("pipeline_frac"),
+            "ms_per_step_levels": (leg.get("alt_levels") or {}).get("ms_per_step"), "pipeline_frac_levels": (leg.get("alt_levels") or {}).get("pipeline_frac"),
             "windows": len(leg["windows"]), "graph_gen_s": round(c.gen_s, 2), **(leg["cache_info"] or {}), **(leg["xgmi"] or {})}
 
 
@@ -674,11 +675,36 @@ def run_leg(c, unified, headline, min_time=None, with_alt=False):
 
     census = [True]   # copy nc/ec of the batch into the log (the untimed census pass only: two 64-byte copies cost ~14 us of stream time)
 
-    def step(i, timed_idx=None, overlap=overlap):
+    def step_levels(i, it):
+        """The `legion` server's schedule (runner.cpp, Server.cu:301-328 + its depth-2 pipes): the rows of level l are gathered on the
+        second stream behind the event of the op that produced them, while hop l + 1 -- and then the next batch, which uses the other
+        pipe -- is sampled on the first; a pipe is reused only after its last gather finished.  Untimed per kernel (whole windows only)."""
+        q = i % depth
+        L.GPUMemoryPool_SetCurrentPipe(pool, q)
+        L.GPUMemoryPool_SetCurrentMode(pool, K.TRAINMODE)
+        if used[q]:
+            L.d_stream_wait_event(stream, ev_gathered[q])
+        L.batch_generator_kernel(stream, eng.noder, eng.cache, pool, B, it, me, me, K.TRAINMODE)
+        L.d_event_record(ev_hop[0], stream)
+        L.d_stream_wait_event(gstream2, ev_hop[0])
+        L.get_feature_kernel(gstream2, eng.cache, eng.noder, pool, me, 1, 1)
+        for h in range(H):
+            L.GPU_Random_Sampling(stream, eng.graph, eng.cache, pool, fan[h], 2 * h + 2, 0)
+            L.d_event_record(ev_hop[h + 1], stream)
+            L.d_stream_wait_event(gstream2, ev_hop[h + 1])
+            L.get_feature_kernel(gstream2, eng.cache, eng.noder, pool, me, 2 * h + 3, 1)
+        L.d_event_record(ev_gathered[q], gstream2)
+        used[q] = True
+        L.make_update_plan(stream, eng.graph, eng.cache, pool, me, K.TRAINMODE)
+        L.update_cache(stream, eng.cache, eng.noder, pool, me, K.TRAINMODE)
+
+    def step(i, timed_idx=None, overlap=overlap, levels=False):
         """One mini-batch.  overlap: depth-2 pipes (the reference's PIPELINE_DEPTH), the sampler of batch
         i+1 runs on `stream` while the gather of batch i runs on `gstream`; a pipe's buffers are reused
-        only after its gather finished."""
+        only after its gather finished.  levels: step_levels."""
         it = i % steps_avail
+        if levels:
+            return step_levels(i, it)
         q = i % depth if overlap else 0
         gstream = gstream2 if overlap else stream
         if intra and not overlap:
@@ -806,7 +832,7 @@ def run_leg(c, unified, headline, min_time=None, with_alt=False):
 
     leg = dict(unified=unified, cache_info=cache_info, elapsed=elapsed_max, windows=[round(w * 1e3, 4) for w in win_max],
                job_edges=job_edges, job_nodes=job_nodes, job_bytes=job_bytes, samp_bytes=samp_bytes, gather_bytes=gather_bytes,
-               u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, graph=None,
+               u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, alt_levels=None, graph=None,
                xgmi=None, exchange=exchange, xgmi_hw=xgmi_hw)
 
     # the other schedule on the very same K batches, in windows like the headline (median window): with --pipeline serial this
@@ -822,6 +848,18 @@ def run_leg(c, unified, headline, min_time=None, with_alt=False):
                       "value": round(job_edges / alt_max, 1), "unit": "edges/s", "windows": len(alt_w),
                       "feature_GBps": round(job_nodes * 4 * F / alt_max / 1e9, 2),
                       "pipeline_frac": round(job_bytes / alt_max / 1e9 / (HBM_PEAK_GBPS * world), 4)}
+        if not overlap:
+            # ... and the server's own two-stream schedule: per-level gathers behind the hop events + depth-2 pipes
+            drain()
+            used[:] = [False] * depth
+            lv_w = [window(timed=False, levels=True) for _ in range(max(1, a_reps))]
+            lv_max = float(np.median(D.aggregate_max_vec(lv_w, world, device=dev)))
+            leg["alt_levels"] = {"pipeline": "levels: per-level gathers on stream 1 behind the hop events, next batch on the other pipe (the `legion` server's loop)",
+                                 "ms_per_step": round(lv_max / K_steps * 1e3, 4), "value": round(job_edges / lv_max, 1), "unit": "edges/s",
+                                 "windows": len(lv_w), "feature_GBps": round(job_nodes * 4 * F / lv_max / 1e9, 2),
+                                 "pipeline_frac": round(job_bytes / lv_max / 1e9 / (HBM_PEAK_GBPS * world), 4)}
+            drain()
+            used[:] = [False] * depth
 
     # the serial schedule again, recorded once as a hipGraph and replayed with one launch per batch (same K batches)
     if headline and not per_level and not intra and not args.headline_only and world == 1:   # informational leg: N = 1 only, never fatal
@@ -1040,6 +1078,7 @@ def headline_line(c, leg):
         "value_overlap": (leg["alt"] or {}).get("value") if (leg["alt"] or {}).get("pipeline") == "overlap" else None,
         "ms_per_step_overlap": (leg["alt"] or {}).get("ms_per_step") if (leg["alt"] or {}).get("pipeline") == "overlap" else None,
         "alt_schedule": leg["alt"],
+        "alt_schedule_levels": leg.get("alt_levels"),
         "graph_replay": leg["graph"],
         "legs_failed": [],          # legs after the headline that raised or hung (N > 1): [] = every leg in this line is valid
         "extra_legs": {},

@@ -81,7 +81,9 @@ def main():
     ap.add_argument("--fanout", default="25,10")
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "graph_trace"))
+    ap.add_argument("--variants", default="plain,graph1,graph2,graph3")
     a = ap.parse_args()
+    a.out = os.path.abspath(a.out)
     import dataclasses
     import legion1_amd.synth as S
     ds = S.generate(S.spec_for(a.workload, scale=a.scale))
@@ -97,6 +99,8 @@ def main():
     hops = len(a.fanout.split(","))
     for name, extra, traced in (("plain", {}, False), ("graph1", {"LEGION_BATCH_GRAPH": "1"}, False), ("graph2", {"LEGION_BATCH_GRAPH": "2"}, False), ("graph3", {"LEGION_BATCH_GRAPH": "3"}, False),
                                 ("plain", {}, True), ("graph1", {"LEGION_BATCH_GRAPH": "1"}, True), ("graph2", {"LEGION_BATCH_GRAPH": "2"}, True), ("graph3", {"LEGION_BATCH_GRAPH": "3"}, True)):
+        if name not in a.variants.split(","):
+            continue
         ns = "gt%d_%s%d_" % (os.getpid(), name, traced)
         env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", TMPDIR="/tmp", **extra)
         d = os.path.join(a.out, name)

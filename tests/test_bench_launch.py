@@ -213,3 +213,23 @@ def test_a_rank_ignores_its_own_leg_level_announcement():
                       "    time.sleep(30.0)\n"
                       "print('RES', g.run('lp', 20.0, leg))\n")
     assert r.returncode == bench.LEG_HUNG_EXIT and "a peer raised" in r.stdout and "RES" not in r.stdout
+
+
+# ---- which legs the one command runs (every single-GPU-measurable BASELINE path in the N = 1 line) ----------------
+def test_extra_leg_plan():
+    class C:
+        pass
+
+    def names(world, *flags):
+        c = C()
+        c.world, c.args = world, bench.parse(list(flags))
+        return bench.extra_leg_names(c)
+    assert names(1) == ["lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]     # legs that re-use the headline graph first
+    assert names(8) == ["lp", "uk_union"] and names(2) == ["lp", "uk_union"]                              # the multi-GPU command is frozen (r03 keys)
+    assert names(1, "--extra-legs", "none") == [] and names(8, "--extra-legs", "none") == []
+    assert names(1, "--workload", "products") == [] and names(1, "--task", "lp") == [] and names(1, "--headline-only") == []   # auto: default workload only
+    assert names(1, "--extra-legs", "products_3hop,lp") == ["lp", "products_3hop"]                      # explicit lists run in the canonical order
+    assert names(4, "--extra-legs", "uk_union") == ["uk_union"]
+    import pytest
+    with pytest.raises(SystemExit):
+        names(1, "--extra-legs", "nonsense")

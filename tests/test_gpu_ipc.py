@@ -89,13 +89,15 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
     assert ("Tables stay in pinned host memory" if tables == "host" else "Tables replicated into HBM") in text
 
 
-@pytest.mark.parametrize("peer_gather", ["in-kernel", "exchange"])
+@pytest.mark.parametrize("peer_gather", ["in-kernel", "exchange", "graph3"])
 def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle, peer_gather):
     """`legion 2 1`: two logical GPUs in ONE server process (a thread per GPU, Server.cu:119-127), Kg = 2 unified
     cache with in-kernel peer reads (both logical GPUs map onto the box's single device), one trainer process
     per GPU.  Each trainer must see exactly its partition's batches (tid % 2 split, GPUGraphStore.cu:332-346).
     peer_gather = exchange: the same server with $LEGION_PEER_GATHER=exchange -- the peers' rows arrive as hipMemcpyPeerAsync
-    bulk copies (peer_exchange.cpp), driven concurrently by the two runner threads, each launching on the other's device."""
+    bulk copies (peer_exchange.cpp), driven concurrently by the two runner threads, each launching on the other's device.
+    graph3: in-kernel peer reads under $LEGION_BATCH_GRAPH=3 -- every runner thread replays its sampler graphs and launches one
+    cached gather over all rows on its second stream."""
     spec = synth.spec_for("products", scale=0.004)
     ds = synth.generate(spec)
     data = str(tmp_path / "ds") + "/"
@@ -110,6 +112,8 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle, peer
     env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_TABLES="host")
     if peer_gather == "exchange":
         env["LEGION_PEER_GATHER"] = "exchange"
+    if peer_gather == "graph3":
+        env["LEGION_BATCH_GRAPH"] = "3"
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:
         server = subprocess.Popen([SERVER, str(G), "1", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT,

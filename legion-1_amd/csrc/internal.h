@@ -45,10 +45,6 @@ constexpr int kTile = LEGION_KTILE;            // sampler slots per workgroup ti
 constexpr int kBlock = 256;                    // threads per workgroup
 static_assert(kTile >= kBlock && kTile <= 2048 && (kTile & (kTile - 1)) == 0, "LEGION_KTILE: a power of two in [256, 2048] (k_sample stages 16 bytes of row descriptor per slot in static LDS)");
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
-// k_write packs the (edges, nodes) counted in front of a tile group INSIDE its prefix block into 16 bits each: a block of
-// 2^lpb groups of 2^gshift tiles may hold at most 65536 / kTile tiles, i.e. lpb + gshift <= kPrefixBits (6 at kTile = 1024)
-constexpr int kPrefixBits = 16 - ilog2_c(kTile);
-static_assert((1 << kPrefixBits) * kTile <= 65536 && kPrefixBits >= 4, "16-bit in-block tile prefix would overflow for this LEGION_KTILE");
 constexpr int kMaxParts = LEGION_MAX_DEVICE;
 
 // minstd_rand arithmetic (thrust::minstd_rand: x <- 48271 x mod 2^31-1), shared by the sampler and the generators
@@ -126,6 +122,8 @@ struct SamplerBuffers {
     bool aux_prepared;      // aux already holds -1 for nc[2] * count slots
     int32_t* tile_edge;     // i32[max tiles]
     int32_t* tile_node;     // i32[max tiles]
+    int2* tile_pre;         // int2[max tiles]: (edges, new nodes) in front of a tile inside its k_mark chunk
+    int2* chunk_tot;        // int2[kMaxChunks]: totals of the k_mark chunks
     HopState* hop_state;
     unsigned long long* edge_access_time; // pre-sampling only (may be null)
 };
@@ -235,6 +233,8 @@ struct GPUMemoryPool {
     int32_t aux_ready_hop = 0, aux_ready_count = 0; // the launch before prepared aux2[hop & 1] for this fan-out
     int32_t* tile_edge = nullptr;
     int32_t* tile_node = nullptr;
+    int2* tile_pre = nullptr;
+    int2* chunk_tot = nullptr;
     legion::HopState* hop_state = nullptr;
     int32_t* cache_search_buffer = nullptr;
     const float** row_ptr = nullptr;  // [num_ids] row source addresses of the running gather (cached configurations)

@@ -20,8 +20,9 @@
 //                 <= -2 lost to slot -2-x.  Repeated draws of a row are settled in-wave; a claim that
 //                 replaces a larger slot's claim writes that slot's state ("you lost to me");
 //      k_mark   : streaming pass over the states: a slot still at -1 kept its claim = a new node; it gets its
-//                 rank among the new nodes of its tile, the tile its count (no table probe);
-//      k_write  : every workgroup builds the exclusive prefix of the tile counts in LDS (no scan launch),
+//                 rank among the new nodes of its tile, the tile its count (no table probe); a workgroup runs a contiguous
+//                 chunk of tiles and leaves each tile's (edges, new nodes) prefix inside the chunk + the chunk totals;
+//      k_write  : every workgroup scans k_mark's <= 2048 chunk totals in LDS (no scan launch; + one 8-byte in-chunk prefix per tile),
 //                 then ordered compaction (wave ballot + popcount prefix, one LDS exchange per tile)
 //                 appends edges / new nodes at their canonical positions and both COO offsets -- an edge
 //                 that lost its claim follows loser -> winner through the slot states and computes the
@@ -327,21 +328,37 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // "winner, r-th new node of this tile" (enc_win): with the per-tile counts that is the node's final position,
 // computable by ANY workgroup of k_write -- which is what lets k_write resolve the edges that lost their claim
 // itself (round 1 needed a fourth launch per hop, k_resolve, for that).
-constexpr int32_t kWinBase = 0x40000000;
-// k_write keeps <= 26 KB of tile prefix in LDS: one entry per tile up to 6.3 M slots per hop, per 2 tiles up to 12.6 M, ...
-// Swept on MI355X (profiles/r02_write_lds_sweep.md): 12288 entries (one per tile at the 10 M-slot bound of a {25,10,5} hop 3,
-// 42 KB, 3 workgroups per CU) 19.7 us avg / 108 us at the products shape; 6144 (pairs of tiles, 22 KB, 6 per CU) 17.9 / 91; 3072: 18.6; 1536: 19.0 / 116
-constexpr int kWriteEntries = 6144;
+constexpr int32_t kWinBase = 0x40000000;   // loser states are -2 - slot with slot < 2^30; winner ranks sit below them
+
 // cached gather: 0 = lookup pass (k_row_ptrs), U > 0 = k_gather_lookup<U>.  Same box, papers100M shape, 25 % of the rows cached: pass 416-423 us,
 // U = 1: 455, U = 2: 412-414, U = 4: 418 (profiles/r04_cached_gather.md) -- the probes themselves (1.94 M random 4-byte reads of a 444 MB map) bound it
-constexpr int kGatherLookupDefault = 2; // loser states are -2 - slot with slot < 2^30; winners sit below them
+constexpr int kGatherLookupDefault = 2;
 __device__ inline int32_t enc_win(int32_t r) { return -2 - (kWinBase + r); }
 __device__ inline bool is_win(int32_t v) { return v <= -2 - kWinBase; }
 __device__ inline int32_t win_rank(int32_t v) { return -2 - v - kWinBase; }
 
+// Tile prefixes without a scan launch and without every workgroup of k_write reading every tile count: k_mark gives each of its
+// workgroups a CONTIGUOUS chunk of T = ceil(tiles / workgroups) tiles, so a workgroup knows the (edges, new nodes) counted in front of each of
+// its tiles INSIDE its chunk (tile_pre) and the chunk's totals (chunk_tot); k_write scans the <= kMaxChunks chunk totals in LDS (8-16 KB of
+// shared reads per workgroup instead of every tile count: 35-70 KB at 4-9 k tiles, re-read by all 1536 workgroups at once -- one such prefix
+// build cost 6.8 / 16.3 us per launch at the papers100M / products hop 3, profiles/r04_sampler.md) and adds tile_pre[t] of any tile it needs.
+constexpr int kMaxChunks = 2048;   // >= the largest k_mark grid (256 CUs x 8 workgroups)
+__host__ __device__ inline FastDiv make_fastdiv(uint32_t div)
+{
+    FastDiv f;
+    f.d = div ? div : 1;
+    if (f.d == 1) { f.m = 0; f.s = 0; return f; }
+    uint32_t l = 0;
+    while ((1ull << l) < f.d) l++;
+    f.m = (uint32_t)(((1ull << (31 + l)) / f.d) + 1ull);
+    f.s = 31 + l;
+    return f;
+}
+
 __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc, const int32_t* __restrict__ ec,
-                                                 int32_t count, int32_t* __restrict__ aux,
-                                                 int32_t* __restrict__ tile_node, HopState* __restrict__ hs)
+                                                 int32_t count, int32_t* __restrict__ aux, const int32_t* __restrict__ tile_edge,
+                                                 int32_t* __restrict__ tile_node, int2* __restrict__ tile_pre,
+                                                 int2* __restrict__ chunk_tot, HopState* __restrict__ hs)
 {
     constexpr int S = kTile / kBlock, W = kBlock / 64;
     __shared__ int32_t s_c[S * W];
@@ -357,29 +374,35 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
         h.in_off = ec[2]; h.n_in = nc[2]; h.slots = total; h.pad = 0;
         *hs = h;
     }
+    const int32_t T = (n_tiles + (int32_t)gridDim.x - 1) / (int32_t)gridDim.x;     // tiles per chunk (k_write derives the same T)
+    const int32_t t0 = (int32_t)blockIdx.x * T, t1 = min(t0 + T, n_tiles);
+    if (t0 >= n_tiles) return;
     // the slot states of the NEXT tile of this workgroup are fetched before the current one is ranked: the loads overlap the
     // two barriers and the stores of the current tile (a workgroup runs 1-5 tiles; the pass is a chain of short latencies)
     int32_t nxt[S];
 #pragma unroll
     for (int s = 0; s < S; s++) {
-        const int64_t idx = (int64_t)blockIdx.x * kTile + threadIdx.x + kBlock * s;
-        nxt[s] = ((int32_t)blockIdx.x < n_tiles && idx < total) ? aux[idx] : 0;
+        const int64_t idx = (int64_t)t0 * kTile + threadIdx.x + kBlock * s;
+        nxt[s] = idx < total ? aux[idx] : 0;
     }
-    for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int32_t te_next = threadIdx.x == 0 ? tile_edge[t0] : 0, run_e = 0, run_n = 0;   // thread 0 keeps the chunk's running sums
+    for (int32_t tile = t0; tile < t1; tile++) {
         bool win[S];
         int32_t rk[S];
+        const int32_t te = te_next;
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
             win[s] = idx < total && nxt[s] == -1;
         }
         {
-            const int64_t nt = (int64_t)tile + gridDim.x;
+            const int64_t nt = (int64_t)tile + 1;
 #pragma unroll
             for (int s = 0; s < S; s++) {
                 const int64_t idx = nt * kTile + threadIdx.x + kBlock * s;
-                nxt[s] = (nt < n_tiles && idx < total) ? aux[idx] : 0;
+                nxt[s] = (nt < t1 && idx < total) ? aux[idx] : 0;
             }
+            if (threadIdx.x == 0 && nt < t1) te_next = tile_edge[nt];
         }
 #pragma unroll
         for (int s = 0; s < S; s++) {
@@ -399,9 +422,14 @@ __global__ __launch_bounds__(kBlock) void k_mark(const int32_t* __restrict__ nc,
 #pragma unroll
         for (int s = 0; s < S; s++)
             if (win[s]) aux[tile * kTile + threadIdx.x + kBlock * s] = enc_win(before[s] + rk[s]);
-        if (threadIdx.x == 0) tile_node[tile] = run;
+        if (threadIdx.x == 0) {
+            tile_node[tile] = run;
+            tile_pre[tile] = make_int2(run_e, run_n);      // in front of this tile inside its chunk
+            run_e += te; run_n += run;
+        }
         __syncthreads();
     }
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = make_int2(run_e, run_n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -444,9 +472,9 @@ struct WriteArgs {
     int32_t op_id;
     const BatchCtl* ctl;
     int32_t last_hop;       // positions of the nodes found in the last hop are never looked up through the table
-    int32_t gshift;         // the LDS prefix holds one entry per 2^gshift tiles (sized from the static slot bound)
-    int32_t lds_entries;    // entries of the dynamic LDS prefix array
-    int32_t lpb;            // log2 of the groups per prefix block: min(5, kPrefixBits - gshift)
+    const int2* tile_pre;   // k_mark: (edges, new nodes) in front of a tile inside its chunk
+    const int2* chunk_tot;  // k_mark: totals of chunk c = tiles [c * T, (c + 1) * T)
+    int32_t mark_grid;      // workgroups of k_mark: T = ceil(tiles / mark_grid)
     int32_t* aux_next;      // slot states of the next hop (the other buffer), set to "claim pending" here
     int32_t next_count;     // fan-out of the next hop (0: none)
     int32_t aux_cap;
@@ -455,15 +483,11 @@ struct WriteArgs {
 __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
 {
     constexpr int S = kTile / kBlock, W = kBlock / 64;
-    // Exclusive prefix of the per-tile edge and new-node counts, once per workgroup, in LDS: the workgroup needs it for
-    // its own tiles AND (nodes) for the tile of any winner one of its losing edges points at -- no scan launch, no
-    // inter-workgroup hand-off (device-scope fences cost an L2 write-back + invalidate per XCD: profiles/r01_gather_sweep.md).
-    // Layout: one entry per group of 2^gshift tiles (gshift == 0 unless the hop's static bound exceeds kWriteEntries
-    // tiles: occupancy beats granularity, see kWriteEntries), groups in blocks of kPB = 2^lpb: s_tile[g] = (edges | nodes << 16) in front of group g INSIDE its block
-    // (both < 2^16: kPB * 2^gshift <= 2^kPrefixBits tiles of kTile slots, static_assert in internal.h), s_blk[b] = (edges, nodes) in front of block b.
-    extern __shared__ uint32_t s_tile[];
-    int2* const s_blk = reinterpret_cast<int2*>(s_tile + a.lds_entries);
-    const int32_t lpb = a.lpb, kPB = 1 << lpb;
+    // (edges, new nodes) counted in front of a tile = exclusive prefix over the chunk totals of k_mark, built once per workgroup in
+    // LDS (<= kMaxChunks entries: one coalesced round of loads), + tile_pre[t] (one 8-byte read, issued next to the other loads of
+    // the tile or of the losing edge that needs it).  No scan launch, no inter-workgroup hand-off (device-scope fences cost an L2
+    // write-back + invalidate per XCD: profiles/r01_gather_sweep.md).
+    __shared__ int2 s_chunk[kMaxChunks];
     __shared__ int32_t s_e[S * W];
     __shared__ int2 s_scan[W];
     const HopState h = *a.hs;
@@ -477,35 +501,21 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
         return;
     }
     if ((int32_t)blockIdx.x >= n_tiles) return;
-    const int32_t gmask = (1 << a.gshift) - 1;
-    const int32_t n_groups = (n_tiles + gmask) >> a.gshift;
-    const int32_t n_blocks = (n_groups + kPB - 1) >> lpb;
+    const int32_t T = (n_tiles + a.mark_grid - 1) / a.mark_grid;   // tiles per chunk, as k_mark derived it
+    const FastDiv div_t = make_fastdiv((uint32_t)T);
+    const int32_t n_chunks = (n_tiles + T - 1) / T;                // <= mark_grid <= kMaxChunks
     {
-        // a wave scans 64 / kPB blocks per step: lane l owns group (l & (kPB - 1)) of block b0 + (l >> lpb)
-        // (coalesced loads, segmented shuffle scan)
-        const int32_t bpw = 64 >> lpb, sub = lane & (kPB - 1);
-        for (int32_t b0 = wave * bpw; b0 < n_blocks; b0 += bpw * W) {
-            const int32_t blk = b0 + (lane >> lpb);
-            const int32_t g = blk * kPB + sub;
-            int32_t ve = 0, vn = 0;
-            if (g < n_groups) {
-                const int32_t te = min((g + 1) << a.gshift, n_tiles);
-                for (int32_t t = g << a.gshift; t < te; t++) { ve += a.tile_edge[t]; vn += a.tile_node[t]; }
-            }
-            int32_t ie = ve, in = vn;
-            for (int o = 1; o < kPB; o <<= 1) {
-                const int32_t ue = __shfl_up(ie, o), un = __shfl_up(in, o);
-                if (sub >= o) { ie += ue; in += un; }
-            }
-            if (g < n_groups) s_tile[g] = (uint32_t)(ie - ve) | ((uint32_t)(in - vn) << 16);
-            if (sub == kPB - 1 && blk < n_blocks) s_blk[blk] = make_int2(ie, in); // block totals
-        }
-        __syncthreads();
-        // exclusive scan of the block totals (a few per thread)
-        const int32_t per = (n_blocks + kBlock - 1) / kBlock;
-        const int32_t q0 = min((int32_t)threadIdx.x * per, n_blocks), q1 = min(q0 + per, n_blocks);
+        constexpr int PER = kMaxChunks / kBlock;                    // consecutive chunks per thread
+        const int32_t q0 = (int32_t)threadIdx.x * PER;
+        int2 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) v[u] = a.chunk_tot[min(q0 + u, n_chunks - 1)];   // unconditional: all in flight together
         int32_t se = 0, sn = 0;
-        for (int32_t q = q0; q < q1; q++) { se += s_blk[q].x; sn += s_blk[q].y; }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            if (q0 + u >= n_chunks) v[u] = make_int2(0, 0);
+            se += v[u].x; sn += v[u].y;
+        }
         int32_t ie = se, in = sn;
         for (int o = 1; o < 64; o <<= 1) {
             const int32_t ue = __shfl_up(ie, o), un = __shfl_up(in, o);
@@ -517,27 +527,25 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
 #pragma unroll
         for (int w = 0; w < W; w++)
             if (w < wave) { run_e += s_scan[w].x; run_n += s_scan[w].y; }
-        for (int32_t q = q0; q < q1; q++) { const int2 v = s_blk[q]; s_blk[q] = make_int2(run_e, run_n); run_e += v.x; run_n += v.y; }
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            if (q0 + u < n_chunks) s_chunk[q0 + u] = make_int2(run_e, run_n);
+            run_e += v[u].x; run_n += v[u].y;
+        }
         __syncthreads();
     }
-    // (edges, new nodes) in front of tile t
-    auto prefix_of = [&](int32_t t, int32_t& pe, int32_t& pn) {
-        const int32_t g = t >> a.gshift;
-        const uint32_t pk = s_tile[g];
-        const int2 bb = s_blk[g >> lpb];
-        pe = bb.x + (int32_t)(pk & 0xFFFFu);
-        pn = bb.y + (int32_t)(pk >> 16);
-        for (int32_t u = t & ~gmask; u < t; u++) { pe += a.tile_edge[u]; pn += a.tile_node[u]; }
-    };
+    // new nodes in front of tile t (what an edge that lost its claim needs of its winner's tile); `pre` = tile_pre[t]
+    auto nodes_before = [&](int32_t t, int32_t pre_n_in_chunk) { return s_chunk[fdiv((uint32_t)t, div_t)].y + pre_n_in_chunk; };
 
     for (int32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        int32_t pre_e, pre_n;
-        prefix_of(tile, pre_e, pre_n);
+        const int2 own = a.tile_pre[tile], own_chunk = s_chunk[fdiv((uint32_t)tile, div_t)];
+        const int32_t pre_e = own_chunk.x + own.x, pre_n = own_chunk.y + own.y;
         const int32_t tile_e = a.tile_edge[tile];
         const int32_t ebase = h.edge_base + pre_e;
         const int32_t nbase = h.node_base + pre_n;
         // ---- loads first, all S slots of the thread in flight together (nothing below this block reads global memory) ----
-        int32_t c[S], so[S], dpos[S], w[S], re[S];
+        int32_t c[S], so[S], dpos[S], w[S], re[S], wpre[S];
+        const int32_t* __restrict__ pre_n_of = reinterpret_cast<const int32_t*>(a.tile_pre) + 1;   // tile_pre[t].y at [2 * t]
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const int32_t idx = tile * kTile + threadIdx.x + kBlock * s;
@@ -557,11 +565,13 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             // triples), where the reference's position_map keeps the last occurrence -- read it (<= B*f probes).
             dpos[s] = (a.op_id == 2) ? (int32_t)(uint32_t)a.pos_map[a.sampled_ids[i]] : a.agg_src_off[h.in_off + i];
             // lost the claim: first link of loser -> (earlier loser ->)* winner or known node
-            if (so[s] < -1 && !is_win(so[s])) { w[s] = -2 - so[s]; so[s] = a.aux[w[s]]; }
+            // (with the in-chunk node prefix of that slot's tile, should it turn out to be the winner: same round trip)
+            wpre[s] = 0;
+            if (so[s] < -1 && !is_win(so[s])) { w[s] = -2 - so[s]; so[s] = a.aux[w[s]]; wpre[s] = pre_n_of[2 * (w[s] / kTile)]; }
         }
 #pragma unroll
         for (int s = 0; s < S; s++) // longer chains are rare: follow them one slot at a time
-            while (w[s] >= 0 && so[s] < -1 && !is_win(so[s])) { w[s] = -2 - so[s]; so[s] = a.aux[w[s]]; }
+            while (w[s] >= 0 && so[s] < -1 && !is_win(so[s])) { w[s] = -2 - so[s]; so[s] = a.aux[w[s]]; wpre[s] = pre_n_of[2 * (w[s] / kTile)]; }
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const unsigned long long be = __ballot(c[s] != -1);
@@ -588,11 +598,8 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             // src-side offset (construct_graph, Kernels.cu:456-460) = position of the sampled neighbour
             int32_t p = so[s];
             if (w[s] >= 0) {         // an edge that lost its claim
-                if (p < -1) {        // ... to a new node: the winner's position from ITS tile's prefix and its rank
-                    int32_t pe_w, pn_w;
-                    prefix_of(w[s] / kTile, pe_w, pn_w);
-                    p = h.node_base + pn_w + win_rank(p);
-                }
+                if (p < -1)         // ... to a new node: the winner's position from ITS tile's prefix and its rank
+                    p = h.node_base + nodes_before(w[s] / kTile, wpre[s]) + win_rank(p);
             } else if (is_win(p)) {  // this slot discovered the node: k_mark ranked it inside the tile
                 p = nbase + win_rank(p);
                 a.sampled_ids[p] = dst;
@@ -1201,27 +1208,18 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
     else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
-    k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.aux, b.tile_node, b.hop_state);
+    if (grid > kMaxChunks) { LEGION_ARG_ERROR("GPU_Random_Sampling: more k_mark workgroups than chunk slots"); return; }
+    k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.aux, b.tile_edge, b.tile_node, b.tile_pre, b.chunk_tot, b.hop_state);
     HIP_CHECK_LAST();
     WriteArgs w;
     w.hs = b.hop_state; w.nc = b.nc; w.ec = b.ec; w.hops = hops; w.cand = b.cand; w.aux = b.aux; w.ctl = b.ctl; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
     w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
     w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id; w.last_hop = (op_id / 2 == hops) ? 1 : 0;
     w.aux_next = b.aux_next; w.next_count = b.next_count; w.aux_cap = b.aux_cap;
-    // LDS prefix: one packed entry per 2^gshift tiles (+ one pair per 32 entries), at most kWriteEntries entries
-    w.gshift = 0;
-    while (((max_tiles + (1 << w.gshift) - 1) >> w.gshift) > kWriteEntries) w.gshift++;
-    // lpb >= 1 keeps the block array at <= 4 bytes per entry: <= 48 KB of dynamic LDS at kWriteEntries (64 KB is the limit
-    // of a workgroup without opting in); that covers kWriteEntries * 2^(kPrefixBits - 1) tiles = 201 M slots per hop at kTile = 1024
-    if (w.gshift > kPrefixBits - 1) { LEGION_ARG_ERROR("GPU_Random_Sampling: hop too large for the tile-prefix encoding"); return; }
-    w.lpb = std::min(5, kPrefixBits - w.gshift);
-    w.lds_entries = (((max_tiles + (1 << w.gshift) - 1) >> w.gshift) + 63) & ~63;
-    const size_t lds = (size_t)w.lds_entries * sizeof(uint32_t) + (size_t)(w.lds_entries >> w.lpb) * sizeof(int2);
-    if (lds > 60 * 1024) { LEGION_ARG_ERROR("GPU_Random_Sampling: tile prefix exceeds the workgroup's LDS"); return; }
-    // every workgroup builds the prefix once: launch no more of them than are resident together
-    const int per_cu = std::max(1, std::min(8, (int)((140 * 1024) / (lds + 1024))));
-    const int wgrid = grid_for(max_tiles, 1, per_cu);
-    k_write<<<wgrid, kBlock, lds, s>>>(w);
+    w.tile_pre = b.tile_pre; w.chunk_tot = b.chunk_tot; w.mark_grid = grid;
+    // 17 KB of static LDS (the chunk prefix): 8 workgroups per CU
+    const int wgrid = grid_for(max_tiles, 1, 8);
+    k_write<<<wgrid, kBlock, 0, s>>>(w);
     HIP_CHECK_LAST();
 }
 

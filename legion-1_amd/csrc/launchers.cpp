@@ -120,7 +120,7 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     const int q = p->current_pipe;
     b.sampled_ids = p->sampled_ids[q]; b.agg_src_ids = p->agg_src_ids; b.agg_src_off = p->agg_src_off[q];
     b.agg_dst_off = p->agg_dst_off[q]; b.nc = p->node_counter[q]; b.ec = p->edge_counter[q];
-    b.pos_map = p->pos_map; b.ctl = p->ctl; b.cand = p->cand; b.aux = p->aux2[hop & 1]; b.aux_next = p->aux2[(hop + 1) & 1]; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node;
+    b.pos_map = p->pos_map; b.ctl = p->ctl; b.cand = p->cand; b.aux = p->aux2[hop & 1]; b.aux_next = p->aux2[(hop + 1) & 1]; b.tile_edge = p->tile_edge; b.tile_node = p->tile_node; b.tile_pre = p->tile_pre; b.chunk_tot = p->chunk_tot;
     b.hop_state = p->hop_state; b.edge_access_time = nullptr;
     if (is_presc) {
         // kernel_pre_sampler_optimized: host CSR only + topology hotness (Kernels.cu:636-649)

@@ -568,6 +568,8 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     for (auto& a : p->aux2) HIP_CHECK(hipMalloc(&a, (size_t)p->max_slots * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_edge, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_node, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
+    HIP_CHECK(hipMalloc(&p->tile_pre, (size_t)(p->max_tiles + 1) * sizeof(int2)));
+    HIP_CHECK(hipMalloc(&p->chunk_tot, (size_t)2048 * sizeof(int2)));   // kMaxChunks (kernels.hip)
     HIP_CHECK(hipMalloc(&p->hop_state, sizeof(HopState)));
     HIP_CHECK(hipMalloc(&p->cache_search_buffer, (size_t)p->num_ids * sizeof(int32_t)));
     HIP_CHECK(hipMalloc((void**)&p->row_ptr, (size_t)p->num_ids * sizeof(float*)));
@@ -609,7 +611,7 @@ void GPUMemoryPool_Finalize(GPUMemoryPool* p)
 {
     if (!p || !p->owns_scratch) return;
     GPUMemoryPool_ReleasePeerExchange(p);
-    (void)hipFree(p->pos_map); (void)hipFree(p->cand); for (auto& a : p->aux2) { (void)hipFree(a); a = nullptr; } (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node);
+    (void)hipFree(p->pos_map); (void)hipFree(p->cand); for (auto& a : p->aux2) { (void)hipFree(a); a = nullptr; } (void)hipFree(p->tile_edge); (void)hipFree(p->tile_node); (void)hipFree(p->tile_pre); (void)hipFree(p->chunk_tot); p->tile_pre = p->chunk_tot = nullptr;
     (void)hipFree(p->hop_state); (void)hipFree(p->cache_search_buffer); (void)hipFree((void*)p->row_ptr); p->row_ptr = nullptr; (void)hipFree(p->agg_src_ids);
     (void)hipFree(p->tmp_part_ind); (void)hipFree(p->tmp_part_off); (void)hipFree(p->ctl); p->ctl = nullptr; if (p->rows_seen) { (void)hipHostFree(p->rows_seen); p->rows_seen = nullptr; p->rows_seen_dev = nullptr; }
     p->pos_map = nullptr; p->cand = nullptr; p->tile_edge = p->tile_node = nullptr; p->hop_state = nullptr;

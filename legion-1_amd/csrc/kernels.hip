@@ -1183,7 +1183,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     // are full: 4 workgroups (16 waves) per CU beat 8 by 2-4 % on hop 3 at every shape and tie on the small hops; 3 lose on hop 2
     // (same-box sweep, profiles/r04_sampler.md).  $LEGION_SAMPLE_WG_PER_CU overrides (1..8).
     static const int wg_per_cu = [] { const char* e = getenv("LEGION_SAMPLE_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 4; }();
-    const int grid = grid_for(max_tiles, 1, wg_per_cu);
+    const int grid = std::min(grid_for(max_tiles, 1, wg_per_cu), kMaxChunks);   // one chunk of tiles per k_mark workgroup (see k_mark)
     if (!b.aux_prepared) { // the previous launch prepared the slot states for another fan-out (or there was none)
         k_fill_aux<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.nc, count, b.aux, b.aux_cap);
         HIP_CHECK_LAST();
@@ -1208,7 +1208,6 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
     else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
-    if (grid > kMaxChunks) { LEGION_ARG_ERROR("GPU_Random_Sampling: more k_mark workgroups than chunk slots"); return; }
     k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.aux, b.tile_edge, b.tile_node, b.tile_pre, b.chunk_tot, b.hop_state);
     HIP_CHECK_LAST();
     WriteArgs w;

@@ -255,6 +255,7 @@ struct IPCEnv {
     std::vector<VmmRegion*> vmm;   // feature buffers above the HIP-IPC size limit (chunked, mapped, served over a unix socket)
     bool shm_pinned = false;       // the slab is registered with the runtime: asynchronous copies can target the counter mirror
     bool mirror_fresh[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH] = {};   // IPCEnv_MirrorCounters ran for the batch about to be posted
+    int32_t* mirror_stage[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH] = {};  // slab not page-locked: queued copies land in pinned staging words
 };
 
 extern "C" {
@@ -300,7 +301,8 @@ static void pin_slab(IPCEnv* e)
 {
     if (e->shm_pinned || !e->shm) return;
     const size_t page = (size_t)sysconf(_SC_PAGESIZE), bytes = (sizeof(shmStruct) + page - 1) / page * page;
-    if (hipHostRegister((void*)e->shm, bytes, hipHostRegisterPortable) == hipSuccess) e->shm_pinned = true;
+    const char* no_pin = getenv("LEGION_IPC_NO_PIN");      // test hook: behave as if the runtime refused (the staging path below)
+    if (!(no_pin && no_pin[0] == '1') && hipHostRegister((void*)e->shm, bytes, hipHostRegisterPortable) == hipSuccess) e->shm_pinned = true;
     else (void)hipGetLastError();
     e->shm->ext_mirror_magic = kMirrorMagic;    // the mirror is maintained either way (synchronously in IPCPost if need be)
 }
@@ -463,8 +465,15 @@ void IPCEnv_MirrorCounters(IPCEnv* e, int32_t dev_id, int32_t current_pipe, void
 {
     if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count || e->node_counter[dev_id].empty()) return;
     const int q = current_pipe % e->pipeline_depth;
-    if (!e->shm_pinned) return;     // IPCPost copies synchronously instead
     int32_t* m = (int32_t*)&e->shm->ext_counters[dev_id][q][0];
+    if (!e->shm_pinned) {           // the runtime refused to page-lock the slab: queue the copies into pinned staging words, IPCPost moves them
+        if (!e->mirror_stage[dev_id][q] && hipHostMalloc((void**)&e->mirror_stage[dev_id][q], 32 * sizeof(int32_t), hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            e->mirror_stage[dev_id][q] = nullptr;
+            return;                 // IPCPost copies synchronously instead
+        }
+        m = e->mirror_stage[dev_id][q];
+    }
     HIP_CHECK(hipMemcpyAsync(m, e->node_counter[dev_id][q], 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_CHECK(hipMemcpyAsync(m + 16, e->edge_counter[dev_id][q], 16 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     e->mirror_fresh[dev_id][q] = true;
@@ -476,11 +485,14 @@ void IPCEnv_SetMirror(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t n
     if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count) return;
     const int q = current_pipe % e->pipeline_depth;
     for (int i = 0; i < 16; i++) { e->shm->ext_counters[dev_id][q][i] = nc_fill; e->shm->ext_counters[dev_id][q][16 + i] = ec_fill; }
+    if (e->mirror_stage[dev_id][q]) for (int i = 0; i < 32; i++) e->mirror_stage[dev_id][q][i] = i < 16 ? nc_fill : ec_fill;
     e->mirror_fresh[dev_id][q] = true;
 }
 void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
 {
     const int q = current_pipe % e->pipeline_depth;
+    if (e->shm && e->mirror_fresh[dev_id][q] && !e->shm_pinned && e->mirror_stage[dev_id][q])     // staged by a queued copy the caller has waited for
+        for (int i = 0; i < 32; i++) e->shm->ext_counters[dev_id][q][i] = e->mirror_stage[dev_id][q][i];
     if (e->shm && e->shm->ext_mirror_magic == kMirrorMagic && !e->mirror_fresh[dev_id][q] && !e->node_counter[dev_id].empty()) {
         // a producer that did not queue the mirror copy (a reference-style RunOnce on this library): copy now -- the batch is
         // complete when a pipe is posted, so a blocking copy is correct, merely slower than the queued one
@@ -540,6 +552,7 @@ void IPCEnv_Finalize(IPCEnv* e)
     e->vmm.clear();
     if (e->shm) {
         if (e->shm_pinned) { (void)hipHostUnregister((void*)e->shm); e->shm_pinned = false; }
+        for (auto& dev : e->mirror_stage) for (auto& p : dev) if (p) { (void)hipHostFree(p); p = nullptr; }
         munmap((void*)e->shm, sizeof(shmStruct));
         close(e->shm_fd);
         shm_unlink(shm_name().c_str());

@@ -40,7 +40,7 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
     ds = synth.generate(spec)
     data = str(tmp_path / "ds") + "/"
     synth.write_legion_files(ds, data)
-    B, epochs = 512, 2
+    B, epochs = 512, int(os.environ.get("LEGION_TEST_EPOCHS", "2"))     # soak: LEGION_TEST_EPOCHS=50 checks thousands of served batches
     budget = int(spec.V * spec.F * 4 * budget_frac)
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:

@@ -6,8 +6,8 @@ box (the clique's logical GPUs are mapped onto it with legion_set_device_map; on
      host memory with a capped HBM cache (hits from both shards, misses spill to the host table over PCIe)
   5  link prediction on the papers100M shape ([src | pos | neg] seed thirds with duplicates)
 
-The oracle cannot run these sizes in seconds, so the checks are the size-independent properties of tests/props.py plus
-byte equality of every gathered row with the generator's closed form, split by where the row came from."""
+Checks: the size-independent properties of tests/props.py, byte equality of every gathered row with the generator's closed form, split by
+where the row came from, and -- since round 4 -- every batch word for word against the (OpenMP) oracle run on a host copy of the CSR."""
 import numpy as np
 import pytest
 
@@ -41,6 +41,16 @@ def _clique_engine(K, spec, indptr, indices, feat_ptr, feat_loc, E, parts, B, fa
     return eng
 
 
+def _host_oracle(oracle, spec, indptr, indices, B, fan):
+    """The resident-form oracle on a host copy of the CSR.  The sampler's output does not depend on WHERE a row is read (whole CSR, own or
+    peer fragment: same values, Kernels.cu:392-409) and neither do the gathered rows (a cached row is a copy of the table row), so the
+    resident batch is the expected result of the partitioned / cached configurations too -- bit for bit."""
+    return oracle.OracleRunner(indptr.cpu().numpy(), indices.cpu().numpy(), None, spec.V, spec.F, B, fan, with_features=False)
+
+
+ORACLE_KEYS = ("nc", "ec", "ids", "labels", "src_off", "dst_off")
+
+
 def _row_sources(K, eng, g, ids, cap):
     """Where FindFeat sends each row of a batch of logical GPU g: own shard / peer shard / backing table."""
     L = K.lib()
@@ -53,7 +63,7 @@ def _row_sources(K, eng, g, ids, cap):
 
 
 @pytest.mark.parametrize("G,mode,presc", [(2, 1, 6), (8, 3, 1)])     # G x presc pre-sampled batches must fit the cache (see below)
-def test_papers100m_unified_cache_full_shape(K, synth, G, mode, presc):
+def test_papers100m_unified_cache_full_shape(K, oracle, synth, G, mode, presc):
     """Config 3: 25 % of the V feature rows cached by hotness over the clique (rank-t row on GPU t % Kg, GPUCache.cu:88-108).
     Kg = 2: 7 x 1 GiB chunks per shard.  Kg = 8 (cache_agg_mode 3, GPUCache.cu:593-607 -- the clique BASELINE.json states):
     eight shards of 2 x 1 GiB chunks, eight-way shard tables; every owner's rows are checked byte for byte."""
@@ -68,12 +78,15 @@ def test_papers100m_unified_cache_full_shape(K, synth, G, mode, presc):
     nch = -(-cap * spec.F * 4 // (1 << 30))                          # 7.1 GB / 1.8 GB per shard in 1 GiB chunks
     assert all(L.GPUCache_ShardChunkCount(eng.cache, g) == nch for g in range(G)) and nch == {2: 7, 8: 2}[G]
     rs = np.random.RandomState(3)
+    orc = _host_oracle(oracle, spec, indptr, indices, B, fan)
     for g in (range(G) if G == 2 else (0, 3, 7)):
-        seeds_g = parts[g][0].cpu().numpy()
+        seeds_g, labs_g = parts[g][0].cpu().numpy(), parts[g][1].cpu().numpy()
         for it in (0, presc + 1):           # a batch of the pre-sampling epoch and one the cache has never seen
             eng.run_batch(g, it, per_level=(it == 0))
             res = eng.result(g)
             check_batch(res, spec, synth, B, fan, indptr, indices, seeds_g[it * B:(it + 1) * B], rs)
+            # the cached configuration against the oracle at full shape, word for word
+            assert_batch_equal(orc.run_batch(seeds_g, labs_g, it, gather=False, omp=True), res, keys=ORACLE_KEYS)
             own, peer, miss = _row_sources(K, eng, g, res["ids"], cap)
             # every node of a pre-sampled batch has hotness > 0 and the cache holds more rows than were ever seen, so
             # batch 0 is served from the shards alone; a batch the cache has never seen also misses
@@ -99,7 +112,7 @@ def test_papers100m_unified_cache_full_shape(K, synth, G, mode, presc):
 
 
 @pytest.mark.parametrize("G,mode,host_spill", [(2, 1, True), (8, 3, False)])
-def test_uk_union_sharded_csr_full_shape(K, synth, G, mode, host_spill):
+def test_uk_union_sharded_csr_full_shape(K, oracle, synth, G, mode, host_spill):
     """Config 4: uk-union 2-hop {25,10}; the hottest adjacency rows as partitioned CSR fragments over the clique (several 1 GiB index
     chunks per fragment at Kg = 2: the row_shift / edge_shift chunk tables are exercised at E > 2^32) behind a capped feature cache.
     Kg = 2: the feature table in pinned host memory (137 GB), misses spill over PCIe.  Kg = 8 (cache_agg_mode 3, the clique
@@ -142,12 +155,15 @@ def test_uk_union_sharded_csr_full_shape(K, synth, G, mode, host_spill):
     for b in (d_probe, d_pi, d_po):
         b.free()
     assert all((owner == g).sum() == cap_e for g in range(G))     # rank-t row on GPU t % Kg
+    orc = _host_oracle(oracle, spec, indptr, indices, B, fan)
     for g in (range(G) if G == 2 else (0, 5)):
-        seeds_g = parts[g][0].cpu().numpy()
+        seeds_g, labs_g = parts[g][0].cpu().numpy(), parts[g][1].cpu().numpy()
         for it in (1, presc + 2):
             eng.run_batch(g, it)
             res = eng.result(g)
             levels = check_batch(res, spec, synth, B, fan, indptr, indices, seeds_g[it * B:(it + 1) * B], rs)
+            # the sampler over partitioned CSR fragments (own, peer, whole-CSR rows mixed; E > 2^32) against the oracle, word for word
+            assert_batch_equal(orc.run_batch(seeds_g, labs_g, it, gather=False, omp=True), res, keys=ORACLE_KEYS)
             ids = res["ids"]
             # the sampler expanded rows of all three kinds: own fragment, peer fragments, the whole-CSR replica
             srcs = ids[:levels[0] + levels[1]]
@@ -173,7 +189,7 @@ def test_uk_union_sharded_csr_full_shape(K, synth, G, mode, host_spill):
 
 
 @pytest.mark.parametrize("world,rank", [(2, 1), (8, 5)])
-def test_papers100m_link_prediction_full_shape(K, synth, world, rank):
+def test_papers100m_link_prediction_full_shape(K, oracle, synth, world, rank):
     """Config 5: [src | pos | neg] seed batches at the papers100M shape (11.1 M triples generated on the GPU by
     legion_synth_lp_seeds; the list of logical GPU `rank` of `world`: triples dealt by src % world -- 2 GPUs, and the 8 GPUs
     BASELINE.json states), 3-hop."""
@@ -222,12 +238,15 @@ def test_papers100m_link_prediction_full_shape(K, synth, world, rank):
         assert np.array_equal(batch[:m], s) and np.array_equal(batch[k:k + m], pos) and np.array_equal(batch[2 * k:2 * k + m], neg)
         assert (s % world == rank).all()
     dup_batches = 0
+    orc = _host_oracle(oracle, spec, indptr, indices, B, fan)
+    h_lab = my_lab.cpu().numpy()
     for it in (0, 3, n // B - 1):
         eng.run_batch(0, it)
         res = eng.result(0)
         batch = h_seeds[it * B:(it + 1) * B]
         dup_batches += int(len(np.unique(batch)) < B)
         check_batch(res, spec, synth, B, fan, indptr, indices, batch, rs, distinct_seeds=False)
+        assert_batch_equal(orc.run_batch(h_seeds, h_lab, it, gather=False, omp=True), res, keys=ORACLE_KEYS)   # the per-rank list of a 2 / 8-GPU job
     assert dup_batches > 0          # hot positives repeat inside a batch: the duplicate-seed path really ran
     eng.close()
 

@@ -666,9 +666,9 @@ def test_gpu_generator_matches_numpy(K, synth):
                                                  ("products", [25, 10, 5], True), ("products", [25, 10, 5], False),
                                                  ("papers100M", [25, 10, 5], False), ("papers100M", [25, 10], False),
                                                  ("uk-union", [25, 10, 5], False)])     # uk-union: E = 5.5e9 > 2^32 edge offsets, F = 256
-def test_full_size_properties(K, synth, workload, fan, padded):
-    """BASELINE.json sizes (V up to 111 M, ~64 GB resident): the oracle cannot run there in seconds,
-    so check the size-independent properties every reference execution satisfies.
+def test_full_size_properties(K, oracle, synth, workload, fan, padded):
+    """BASELINE.json sizes (V up to 133 M, up to 160 GB resident): the size-independent properties every reference execution satisfies
+     and, since round 4, the oracle itself on a host copy of the CSR.
     padded: the HBM feature table with legion_row_pitch(F) floats per row (F = 100 -> 128), as bench.py builds it."""
     import torch
     sys_bench = __import__("bench")
@@ -688,9 +688,13 @@ def test_full_size_properties(K, synth, workload, fan, padded):
     seeds = dict(train=[((tr.data_ptr(), spec.n_train), (my_lab.data_ptr(), spec.n_train))])
     eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), spec.V, spec.F, seeds, B, fan, E=E, features_pitch=pitch)
     eng.alloc_features()
+    # round 4: besides the properties below, every batch word for word against the (OpenMP) oracle on a host copy of the CSR
+    orc = oracle.OracleRunner(indptr.cpu().numpy(), indices.cpu().numpy(), None, spec.V, spec.F, B, fan, with_features=False)
+    h_tr, h_lab = tr.cpu().numpy(), my_lab.cpu().numpy()
     for it in (0, 7):
         eng.run_batch(0, it)
         res = eng.result(0)
+        assert_batch_equal(orc.run_batch(h_tr, h_lab, it, gather=False, omp=True), res, keys=("nc", "ec", "ids", "labels", "src_off", "dst_off"))
         nc, ec, ids = res["nc"], res["ec"], res["ids"]
         levels = [int(nc[4 + 2 * l]) for l in range(H + 1)]
         assert nc[5 + 2 * H] == sum(levels) == len(ids) and levels[0] == B

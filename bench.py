@@ -60,9 +60,10 @@ def parse(argv=None):
     ap.add_argument("--extra-legs", default="auto",
                     help="comma list of further legs run by the same processes after the headline (+ unified) leg and reported in the same "
                          "line: lp (BASELINE config 5: link-prediction seed batches on the papers100M graph, B = 7998), uk_union (config 4: "
-                         "uk-union shape, 2-hop {25,10}, CSR sharded over the clique + capped feature cache); N = 1 also cached_gather (config 3's FindFeat + "
-                         "gather path, 25 %% of the rows in a shard), products_2hop / products_3hop (configs 1 / 2), partitioned_csr (= uk_union on one GPU).  "
-                         "auto (default workload only) = lp, cached_gather, products_2hop, products_3hop, partitioned_csr at N = 1; lp, uk_union at N > 1; "
+                         "uk-union shape, 2-hop {25,10}, CSR sharded over the clique + capped feature cache); N = 1 also served (the `legion` server binary + "
+                         "a trainer-side consumer process: the headline batches as a trainer sees them), cached_gather (config 3's FindFeat + "
+                         "gather path, 25 %% of the rows in a shard), products_2hop / products_3hop (configs 1 / 2, each with its own served figure), partitioned_csr (= uk_union on one GPU).  "
+                         "auto (default workload only) = served, lp, cached_gather, products_2hop, products_3hop, partitioned_csr at N = 1; lp, uk_union at N > 1; "
                          "'none' disables")
     ap.add_argument("--extra-timeout", type=float, default=150.0, help="seconds each extra leg may take")
     ap.add_argument("--extra-min-time", type=float, default=1.0, help="--min-time of the extra legs")
@@ -96,6 +97,11 @@ def parse(argv=None):
                          "runs of this workload under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` measure the HBM bytes of the dominant kernel for "
                          "roofline.traffic; off: quote the newest committed profiles/r*_pmc_hbm_traffic.json instead")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch: seconds before the parent gives up on its ranks")
+    ap.add_argument("--time-budget", type=float, default=480.0,
+                    help="seconds the whole command may take (from the start of the first process).  Every leg after the headline gets "
+                         "min(its own timeout, what is left minus a reserve); a leg that would get less than it needs is skipped and named in "
+                         "\"legs_skipped\", so the JSON line is printed before an outer limit (the driver's 600 s) ends the run.  0 = no budget")
+    ap.add_argument("--served-epochs", type=int, default=0, help="`served` leg: epochs the `legion` server runs (0 = sized for about 2 s of serving)")
     return ap.parse_args(argv)
 
 
@@ -131,9 +137,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0):
+def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0, script=None):
     port = free_port()
-    procs = [popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=child_env(os.environ, r, args.gpus, port))
+    environ = dict(os.environ)
+    environ.setdefault("LEGION_BENCH_T0", repr(time.time()))       # the time budget counts from here
+    # stdout carries exactly ONE JSON line (rank 0's): every other rank writes to the parent's stderr, whatever it prints
+    procs = [popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=child_env(environ, r, args.gpus, port),
+                   stdout=None if r == 0 else sys.stderr)
              for r in range(args.gpus)]
     deadline = time.time() + args.launch_timeout
     first_bad = None
@@ -201,13 +211,73 @@ class Ctx:
     """Everything the legs share: the rank's device, the synthetic graph and this rank's seed list."""
 
 
+_LINE_OUT = None      # where the ONE JSON line goes (the process' original stdout); None: sys.stdout
+
+
+def claim_stdout():
+    """From here on file descriptor 1 of this process IS its stderr: whatever the HIP library, RCCL, torch or a child process prints
+    (std::cout chatter of the C++ side, "xGMI Clique ...", "Feature Cache Hit ...") can no longer land inside -- or next to -- the JSON
+    line, which is written to a private duplicate of the original stdout by emit_line()."""
+    global _LINE_OUT
+    if _LINE_OUT is not None:
+        return
+    sys.stdout.flush()
+    _LINE_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    os.environ.setdefault("LEGION_LOG", "stderr")      # the library's own prints go to stderr at the source, too (runtime.cpp)
+
+
+def emit_line(line):
+    out = _LINE_OUT if _LINE_OUT is not None else sys.stdout
+    out.write(json.dumps(line) + "\n")
+    out.flush()
+
+
+class Budget:
+    """--time-budget: what is left of the command's wall-clock allowance.  T0 is the start of the FIRST process of the command (the
+    self-launching parent hands it down in LEGION_BENCH_T0)."""
+    RESERVE_S = 15.0          # kept back for printing the line, the final barrier and process teardown
+
+    def __init__(self, total, t0=None, now=time.time):
+        self.total, self.now = float(total), now
+        self.t0 = float(t0) if t0 is not None else now()
+
+    def left(self):
+        return float("inf") if self.total <= 0 else self.total - (self.now() - self.t0)
+
+    def grant(self, want, least):
+        """Seconds a leg may take: min(want, left - reserve), or 0.0 when that is less than `least` (the leg is skipped)."""
+        got = min(float(want), self.left() - self.RESERVE_S)
+        return got if got >= least else 0.0
+
+
+LEG_LEAST_S = {"unified_cache": 60.0, "served": 40.0}     # a leg that cannot get this much is skipped (default: 30 s)
+
+
+def run_budgeted(c, line, guard, name, want, fn):
+    """Run a leg under the watchdog with what the time budget grants it (rank 0 decides, every rank follows); a leg the budget
+    does not admit is named in "legs_skipped" and the run goes on to print its line."""
+    least = LEG_LEAST_S.get(name, 30.0)
+    grant = c.budget.grant(want, least)
+    if c.world > 1:
+        grant = c.D.allgather_object(grant, c.world)[0]
+    if grant <= 0.0:
+        line.setdefault("legs_skipped", []).append({"leg": name, "why": "time budget: %.0f s of --time-budget %.0f left, the leg needs %.0f + %.0f reserve"
+                                                                       % (max(0.0, c.budget.left()), c.budget.total, least, Budget.RESERVE_S)})
+        return {"skipped": "time budget"}
+    return guard.run(name, grant, fn)
+
+
 def worker(args):
     import torch
     if os.environ.get("LEGION_BENCH_WATCHDOG"):  # debugging aid: dump all Python stacks and exit if stuck
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["LEGION_BENCH_WATCHDOG"]), exit=True)
+    claim_stdout()
     c = Ctx()
     c.args = args
+    c.budget = Budget(args.time_budget, os.environ.get("LEGION_BENCH_T0"))
+    c.children = []       # child processes a leg started (the `served` leg's server and consumer): the watchdog stops them
     c.rank = rank = int(os.environ.get("RANK", "0"))
     c.world = world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,22 +317,36 @@ def worker(args):
     load_workload(c, args.workload)
 
     head = run_leg(c, unified=(args.cache == "unified"), headline=True)
-    line = headline_line(c, head) if rank == 0 else {"legs_failed": [], "extra_legs": {}}
+    c.head = head
+    line = headline_line(c, head) if rank == 0 else {"legs_failed": [], "legs_skipped": [], "extra_legs": {}}
     c.guard = guard = LegGuard(c, line)
 
+    def budgeted(name, want, fn):
+        return run_budgeted(c, line, guard, name, want, fn)
+
     if world > 1 and args.cache == "replicated" and not args.no_unified_leg and args.table == "device":
-        line["unified_cache"] = guard.run("unified_cache", args.unified_timeout,
-                                          lambda: unified_summary(c, run_leg(c, unified=True, headline=False, min_time=args.extra_min_time)))
+        line["unified_cache"] = budgeted("unified_cache", args.unified_timeout,
+                                         lambda: unified_summary(c, run_leg(c, unified=True, headline=False, min_time=args.extra_min_time)))
 
     # measured streaming-copy rate of this box (float4 copy kernel sized like the gather, read + write bytes)
     if rank == 0 and line.get("roofline") is not None:
         line["roofline"]["measured_copy_GBps"] = measure_copy(c)
         if (world == 1 and args.measure_traffic == "auto" and not args.headline_only and args.table == "device" and args.cache == "replicated"
-                and args.gather == "all" and args.pipeline == "serial"):
+                and args.gather == "all" and args.pipeline == "serial" and c.budget.left() > 240.0):   # two passes of <= 90 s each
             got = measure_traffic_in_run(args)
             if got is not None:
                 line["roofline"].update(got)
-    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0:   # reported baseline: N = 1 only
+    if rank == 0 and world > 1 and args.cpu_baseline_seconds > 0 and c.budget.left() > 120.0:
+        # N > 1: the same baseline, short -- sampler + COO only (no 57 GB host copy of the table), <= 5 s of CPU time, on rank 0
+        # while the other ranks wait in the next collective
+        import copy
+        a1 = copy.copy(args)
+        a1.no_cpu_features, a1.cpu_baseline_seconds = True, min(5.0, args.cpu_baseline_seconds)
+        try:
+            line["cpu_baseline"] = run_cpu_baseline(a1, c.spec, c.indptr, c.indices, None, c.mine, c.my_labels, c.B, c.fan, c.steps_avail)
+        except Exception as ex:   # noqa: BLE001 -- reported baseline only
+            line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
+    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0 and c.budget.left() > 150.0:   # reported baseline
         feats = c.feats
         if c.host_table is not None:   # the table already is host memory: view it, no copy
             import ctypes
@@ -273,10 +357,11 @@ def worker(args):
             line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
 
     for name in extra_leg_names(c):      # BASELINE configs 4 and 5, same processes, same line (after everything that needs the headline graph)
-        line["extra_legs"][name] = guard.run(name, args.extra_timeout, lambda name=name: extra_leg(c, name))
+        line["extra_legs"][name] = budgeted(name, args.extra_timeout, lambda name=name: extra_leg(c, name))
 
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        line["time_budget"] = {"budget_s": args.time_budget, "used_s": round(time.time() - c.budget.t0, 1)}
+        emit_line(line)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -359,7 +444,7 @@ class LegGuard:
         in_leg = [True]
         self._part_agreed = False
         fired = threading.Lock()       # timer thread and watcher thread may both get here: the line is printed once
-        hung_exit = LEG_HUNG_EXIT if c.world > 1 else 0   # N = 1: the headline and the finished legs are valid and printed, nobody waits for us
+        hung_exit = LEG_HUNG_EXIT     # at every world size: a watchdog that fires on a process that has touched the GPU never exits 0
 
         def fire(msg=f"did not finish within {timeout:.0f} s"):
             if not fired.acquire(blocking=False):
@@ -374,8 +459,14 @@ class LegGuard:
                         line[name] = err
                     else:
                         line["extra_legs"][name] = err
-                    print(json.dumps(line), flush=True)
+                    emit_line(line)
                 faulthandler.dump_traceback(file=sys.stderr)
+                for ch in getattr(c, "children", []):      # exactly the processes a leg of this run started
+                    try:
+                        if ch.poll() is None:
+                            ch.kill()
+                    except Exception:   # noqa: BLE001
+                        pass
             finally:
                 os._exit(hung_exit)
         timer = threading.Timer(timeout, fire)
@@ -439,7 +530,7 @@ class LegGuard:
             timer.cancel()
 
 
-N1_LEGS = ["lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]   # run order: graph re-use first
+N1_LEGS = ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]   # run order: graph re-use first
 NN_LEGS = ["lp", "uk_union"]
 
 
@@ -485,6 +576,8 @@ def extra_leg(c, name):
         for k in ("spec", "pitch", "indptr", "indices", "feats", "E", "feat_ptr", "feat_loc", "host_table", "mine", "my_labels", "n_mine", "steps_avail", "gen_s"):
             setattr(c, k, getattr(c2, k))      # the previous graph is gone: later legs see this one
 
+    if name == "served":
+        return served_leg(c, c.args.workload, c.fan, c.head)
     if name == "lp":
         # lp_sage.py:87-90: [src | pos | neg] seed thirds; triples dealt to the ranks by src % N; the graph is the headline's
         a.task, a.batch = "lp", (c.B // 3) * 3
@@ -510,6 +603,11 @@ def extra_leg(c, name):
         c2.H = len(c2.fan)
         leg = run_leg(c2, unified=False, headline=False, min_time=a.min_time, with_alt=True)
         out = leg_summary(c2, leg, f"ogbn-products-shape graph, {c2.H}-hop fan-out {c2.fan}, CSR + features resident in HBM (row pitch {c2.pitch} floats)")
+        if c.world == 1 and c.budget.left() > 90.0:
+            try:      # the same batches as a trainer sees them: the server binary on the products shape
+                out["served"] = served_leg(c2, "products", c2.fan, leg)
+            except Exception as ex:   # noqa: BLE001 -- the leg's own numbers stay valid
+                out["served"] = {"error": repr(ex)[:300]}
         if name == "products_2hop" and c.rank == 0 and c.world == 1 and c.args.cpu_baseline_seconds > 0:
             # BASELINE config 1 is this workload on the CPU (DGL's NeighborSampler): the CPU legs on the same graph, bounded
             a.cpu_baseline_seconds = min(4.0, c.args.cpu_baseline_seconds)
@@ -527,6 +625,148 @@ def extra_leg(c, name):
     leg = run_leg(c2, unified=True, headline=False, min_time=a.min_time)
     return leg_summary(c2, leg, f"uk-union-shape graph, CSR sharded over the {c.world}-GPU clique (30 % of the adjacency rows in partitioned "
                                 "fragments) + 10 % of the feature rows in the unified cache, misses from the HBM replica")
+
+
+def served_consumer(argv):
+    """Child process of the `served` leg: a trainer-side null consumer on the C-ABI IPC client (legion_ipc_client_*: what ipc_service
+    binds) -- wait for the batch (sem_w), read its counters, hand the pipe back (sem_r); the reference's get_next / synchronize without a
+    model in between (ipc_cuda_kernel.cu:98-107,178-230).  No torch.  One JSON object on stdout: the arrival time, edges and rows of every batch."""
+    import ctypes as C
+    import legion1_amd.capi as K
+    hops, epochs = int(argv[0]), int(argv[1])
+    lib = K.lib()
+    lib.SetGPUDevice(0)
+    c = C.c_void_p(lib.legion_ipc_client_open(-1))
+    K.check()
+    steps = (C.c_int32 * 3)()
+    lib.legion_ipc_client_steps(c, steps)
+    total = (steps[0] + steps[1]) * epochs + steps[2]
+    nc, ec = (C.c_int32 * 16)(), (C.c_int32 * 16)()
+    t, edges, nodes = [], [], []
+    for _ in range(total):
+        lib.legion_ipc_client_wait(c)
+        lib.legion_ipc_client_read_counters(c, nc, ec)
+        t.append(time.perf_counter())
+        edges.append(ec[2 + hops])
+        nodes.append(nc[5 + 2 * hops])
+        lib.legion_ipc_client_post(c)
+    lib.legion_ipc_client_close(c)
+    sys.stdout.write(json.dumps({"steps": list(steps), "hops": hops, "t": [round(x - t[0], 7) for x in t],
+                                 "edges": edges, "nodes": nodes}) + "\n")
+
+
+def served_schedule_windows(t, train_step, valid_step, epochs, K_steps, warm):
+    """Windows of K consecutive TRAINING batches inside one epoch of the served schedule (CUDA_IPC_Service.cu:219-259: every epoch is
+    train_step training batches, then valid_step validation batches), the first `warm` training batches of epoch 0 left out: seconds per
+    window, measured arrival to arrival (t[i + K - 1] - t[i - 1]), and the global batch numbers each one covers."""
+    per = train_step + valid_step
+    out = []
+    for e in range(epochs):
+        first = e * per + (warm if e == 0 else 0)
+        i = max(first, 1)
+        while i + K_steps <= e * per + train_step:
+            out.append((t[i + K_steps - 1] - t[i - 1], i))
+            i += K_steps
+    return out
+
+
+def served_leg(c, workload, fan, ref_leg):
+    """The whole path through the reference's surface, as a trainer sees it: the `legion` server binary -- started as a
+    FRESH child process, dataset source `synth:<workload>` (the tables generated in its own HBM by the legion_synth_* calls this file uses),
+    pre-sampling epoch, then its default software-pipelined RunOnce loop (runner.cpp; Server.cu:301-328) -- hands every batch of its schedule
+    to a second child, a null consumer on legion_ipc_client_* (CUDA_IPC_Service.cu:289-297 / ipc_cuda_kernel.cu:98-107).  Reported: the
+    consumer-side ms per training batch (median window of K batches, arrival to arrival), edges/s as the consumer sees them, the schedule,
+    and the ratio to `alt_schedule_levels` -- the same two-stream schedule run by this process without the hand-off."""
+    import shutil
+    import tempfile
+    args = c.args
+    if c.world != 1:
+        raise RuntimeError("the served leg runs at N = 1 (one server + one consumer process beside this one)")
+    spec, H, B = c.S.spec_for(workload, scale=args.scale), len(fan), c.B
+    server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
+    if not os.path.exists(server):
+        raise RuntimeError("the server binary is missing: make -C legion-1_amd/csrc legion")
+    train_step = (spec.n_train - 1) // B
+    if train_step < args.steps + args.warmup + 1:
+        raise RuntimeError("the shape has %d training batches per epoch; %d needed" % (train_step, args.steps + args.warmup + 1))
+    ref_ms = ref_leg["elapsed"] / args.steps * 1e3
+    epochs = args.served_epochs or int(max(2, min(50, -(-2000.0 // (train_step * ref_ms)))))
+    n_eval = min(512, spec.n_valid, spec.n_test)         # one validation / test batch per epoch: the schedule stays training batches
+    tmp = tempfile.mkdtemp(prefix="legion_served_")
+    src = "synth:%s" % workload + ("" if (args.scale == 1.0 and args.skew == 205) else ":%r" % args.scale) + ("" if args.skew == 205 else ":%d" % args.skew)
+    meta = os.path.join(tmp, "meta_config")
+    with open(meta, "w") as f:
+        f.write("%s %d %d 0 %d %d %d %d 0 %d 0" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, epochs))
+    env = dict(os.environ, LEGION_IPC_NAMESPACE="bs%d_%d_" % (os.getpid(), len(c.children)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("LEGION_LOG", None)          # the server's log is its stdout (a file here), as with the reference
+    if c.local_rank != 0:
+        env["HIP_VISIBLE_DEVICES"] = str(c.local_rank)
+    log_path = os.path.join(tmp, "server.log")
+    t0 = time.time()
+    srv = cons = None
+    try:
+        with open(log_path, "w") as lf:
+            srv = subprocess.Popen([server, "1", "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=tmp)
+        c.children.append(srv)
+        while "System is ready for serving" not in open(log_path, errors="ignore").read():
+            if srv.poll() is not None:
+                raise RuntimeError("the server exited before serving: " + open(log_path, errors="ignore").read()[-600:])
+            time.sleep(0.05)
+        ready_s = time.time() - t0
+        cons = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--served-consumer", str(H), str(epochs)], env=env,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        c.children.append(cons)
+        out, err = cons.communicate()
+        if cons.returncode != 0:
+            raise RuntimeError("the consumer failed (%d): %s" % (cons.returncode, (out + err)[-600:]))
+        srv.wait(timeout=60)
+        if srv.returncode != 0:
+            raise RuntimeError("the server failed (%d): %s" % (srv.returncode, open(log_path, errors="ignore").read()[-600:]))
+        log_text = open(log_path, errors="ignore").read()
+    finally:
+        for p in (cons, srv):
+            if p is not None and p.poll() is None:
+                p.kill()
+                p.wait()
+        shutil.rmtree(tmp, ignore_errors=True)
+    got = json.loads(out.strip().splitlines()[-1])
+    ts, vs, es = got["steps"]
+    if ts != train_step or len(got["t"]) != (ts + vs) * epochs + es:
+        raise RuntimeError("served schedule %s x %d epochs does not match the shape (train_step %d)" % (got["steps"], epochs, train_step))
+    t, edges, nodes = got["t"], np.asarray(got["edges"], np.int64), np.asarray(got["nodes"], np.int64)
+    wins = served_schedule_windows(t, ts, vs, epochs, args.steps, args.warmup)
+    secs = np.array([w[0] for w in wins])
+    med = float(np.median(secs))
+    is_train = np.array([(b % (ts + vs)) < ts for b in range((ts + vs) * epochs)] + [False] * es)
+    e_mean, n_mean = float(edges[is_train].mean()), float(nodes[is_train].mean())
+    ms = med / args.steps * 1e3
+    # the batches this process timed (W .. W + K - 1 of the seed list) as the trainer received them: same edges, same rows
+    same = None
+    if ref_leg.get("edges_per_step") is not None:
+        W = args.warmup
+        same = bool(np.array_equal(edges[W:W + args.steps], ref_leg["edges_per_step"]) and np.array_equal(nodes[W:W + args.steps], ref_leg["nodes_per_step"]))
+    lv = (ref_leg.get("alt_levels") or {}).get("ms_per_step")
+    ov = (ref_leg.get("alt") or {}).get("ms_per_step") if (ref_leg.get("alt") or {}).get("pipeline") == "overlap" else None
+    train_t = float(sum(t[e * (ts + vs) + ts - 1] - t[max(e * (ts + vs) - 1, 0)] for e in range(epochs)))
+    return {"what": "the `legion` server binary (fresh child process; dataset source %s: tables generated in its HBM; pre-sampling epoch; default "
+                    "software-pipelined RunOnce, 2 streams, depth-2 pipes) serving a null consumer process over shm + semaphores + HIP-IPC buffers "
+                    "(legion_ipc_client_*: wait, read counters, post); times are the CONSUMER's clock, arrival to arrival" % src,
+            "value": round(e_mean / (ms * 1e-3), 1), "unit": "edges/s", "ms_per_step": round(ms, 4),
+            "feature_GBps": round(n_mean * 4 * spec.F / (ms * 1e-3) / 1e9, 2), "batch": B, "fanout": list(fan), "V": spec.V, "F": spec.F,
+            "schedule": {"train_steps": ts, "valid_steps": vs, "test_steps": es, "epochs": epochs, "batches_served": len(t),
+                         "eval_batch_seeds": n_eval},
+            "windows": len(wins), "steps_per_window": args.steps,
+            "window_ms_min_median_max": [round(float(secs.min()) * 1e3, 4), round(med * 1e3, 4), round(float(secs.max()) * 1e3, 4)],
+            "all_training_batches_ms_per_step": round(train_t / (ts * epochs) * 1e3, 4),
+            "edges_per_batch": round(e_mean, 1), "unique_nodes_per_batch": round(n_mean, 1),
+            "served_batches_equal_the_timed_ones": same,
+            "ms_per_step_same_schedule_in_process": lv, "ratio_to_alt_schedule_levels": round(ms / lv, 4) if lv else None,
+            "ms_per_step_overlap_in_process": ov, "ms_per_step_serial_in_process": round(ref_ms, 4),
+            # (sampler + gather algorithmic bytes of the K timed batches, per batch) / served time per batch / 8 TB/s
+            "pipeline_frac": round(float(ref_leg["job_bytes"]) / args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "server_ready_s": round(ready_s, 2), "server_tables": "generated in HBM" if "Tables generated in HBM" in log_text else "?",
+            "server_first_epoch_s": next((float(ln.split(":")[1].split()[0]) for ln in log_text.splitlines() if ln.startswith("First epoch cost")), None),
+            "processes": "bench.py (idle) + legion + consumer"}
 
 
 def leg_summary(c, leg, what):
@@ -832,7 +1072,7 @@ def run_leg(c, unified, headline, min_time=None, with_alt=False):
 
     leg = dict(unified=unified, cache_info=cache_info, elapsed=elapsed_max, windows=[round(w * 1e3, 4) for w in win_max],
                job_edges=job_edges, job_nodes=job_nodes, job_bytes=job_bytes, samp_bytes=samp_bytes, gather_bytes=gather_bytes,
-               u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, alt_levels=None, graph=None,
+               edges_per_step=edges, nodes_per_step=nodes, u_h=u_h, g_ms=np.array(g_ms, dtype=np.float64), per_level=per_level, intra=intra, overlap=overlap, alt=None, alt_levels=None, graph=None,
                xgmi=None, exchange=exchange, xgmi_hw=xgmi_hw)
 
     # the other schedule on the very same K batches, in windows like the headline (median window): with --pipeline serial this
@@ -1080,7 +1320,8 @@ def headline_line(c, leg):
         "alt_schedule": leg["alt"],
         "alt_schedule_levels": leg.get("alt_levels"),
         "graph_replay": leg["graph"],
-        "legs_failed": [],          # legs after the headline that raised or hung (N > 1): [] = every leg in this line is valid
+        "legs_failed": [],          # legs after the headline that raised or hung: [] = every leg in this line is valid
+        "legs_skipped": [],         # legs the time budget did not admit (--time-budget)
         "extra_legs": {},
         "cache": {"mode": "unified" if unified else "replicated", **(leg["cache_info"] or {}), **(leg["xgmi"] or {})},
         "roofline": roofline_of(c, leg),
@@ -1357,6 +1598,8 @@ def run_dgl_baseline(dgl, torch, indptr, indices, feats, ids, B, fan, budget):
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
+    if argv and argv[0] == "--served-consumer":      # internal: the consumer child of the `served` leg
+        return served_consumer(argv[1:])
     args = parse(argv)
     plan = launch_plan(args, os.environ)
     if plan.startswith("error"):

@@ -432,7 +432,12 @@ void legion_ipc_set_namespace(const char* ns);
 typedef struct LegionIPCClient LegionIPCClient;
 LegionIPCClient* legion_ipc_client_open(int32_t device_id);  /* GPUIPCEnv::Initialize, ipc_cuda_kernel.cu:38-96 */
 void legion_ipc_client_wait(LegionIPCClient* c);              /* Wait(), :98-101 */
-void legion_ipc_client_post(LegionIPCClient* c);              /* Post(), :103-107 */
+/* Post(), :103-107 -- behind a hipDeviceSynchronize() of the calling process' current device: work the trainer has queued may still read
+ * the pipe's buffers, and a posted pipe is overwritten by the server.  (The reference got the same bound from the blocking counter copy
+ * of the next get_next; read_counters below reads a host mirror and synchronises nothing, so the wait sits here.) */
+void legion_ipc_client_post(LegionIPCClient* c);
+/* the bare sem_post: for a consumer that has already waited for its own device work (or queues none) */
+void legion_ipc_client_post_nosync(LegionIPCClient* c);
 /* buffer index: 0 ids 1 features 2 labels 3 agg_src 4 agg_dst 5 node_counter 6 edge_counter
  * (CUDA_IPC_Service.cu:169-175,209) of the current pipe */
 void* legion_ipc_client_buffer(LegionIPCClient* c, int32_t which);
@@ -492,6 +497,19 @@ void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, 
 void legion_synth_features_pitched(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F, int32_t pitch);
 void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int32_t classes);
 void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, int32_t V, uint32_t M2, uint32_t C2, int32_t stride, int32_t phase);
+/* The generator's parameters for a named shape ("products" | "papers100M" | "uk-union", legion_server.py:6-37), shrunk by
+ * `scale` in (0, 1] (V and the seed sets; the mean degree stays): the C statement of synth.py spec_for(), field for field
+ * (tests/test_host_logic.py).  Host only, no device call.  0, or -1 (sticky error) for an unknown name / scale. */
+typedef struct LegionSynthSpec {
+    int32_t V, F, classes;
+    int32_t n_train, n_valid, n_test;   /* seed i of the permutation (i * M2 + C2) % V: train = [0, n_train), then valid, then test */
+    uint32_t M, C, M2, C2;              /* neighbour-id scrambler and seed permutation (multipliers coprime with V) */
+    int32_t ladder[26];                 /* degree ladder lo[b] of legion_synth_degrees */
+    double mean_degree;
+} LegionSynthSpec;
+int legion_synth_spec(const char* workload, double scale, LegionSynthSpec* out);
+int32_t legion_synth_label_host(int32_t v, int32_t classes);                           /* == legion_synth_labels, one id, on the host */
+int32_t legion_synth_seed_id_host(int64_t i, int32_t V, uint32_t M2, uint32_t C2);     /* == legion_synth_seed_ids, one index */
 /* streaming-copy kernel used by bench.py to report the measured HBM peak */
 void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes);
 /* the same copy with an explicit variant (profiles/copy_sweep.py): 256-thread workgroups, `unroll` 16-byte chunks in

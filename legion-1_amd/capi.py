@@ -38,6 +38,11 @@ class LegionBuildInfo(C.Structure):
     ]
 
 
+class LegionSynthSpec(C.Structure):
+    _fields_ = [("V", i32), ("F", i32), ("classes", i32), ("n_train", i32), ("n_valid", i32), ("n_test", i32),
+                ("M", u32), ("C", u32), ("M2", u32), ("C2", u32), ("ladder", i32 * 26), ("mean_degree", f64)]
+
+
 class OpParams(C.Structure):
     _fields_ = [("device_id", C.c_int), ("stream", vp), ("event", vp), ("memorypool", vp), ("cache", vp),
                 ("graph", vp), ("noder", vp), ("env", vp), ("neighbor_count", C.c_int), ("is_presc", C.c_int),
@@ -201,7 +206,7 @@ _SIGS = {
     "IPCEnv_Finalize": (None, [vp]), "IPCEnv_GetTrainStep": (i32, [vp]), "IPCEnv_SetHops": (None, [vp, i32]),
     "legion_ipc_set_namespace": (None, [C.c_char_p]),
     "legion_ipc_client_open": (vp, [i32]), "legion_ipc_client_wait": (None, [vp]),
-    "legion_ipc_client_post": (None, [vp]), "legion_ipc_client_buffer": (vp, [vp, i32]),
+    "legion_ipc_client_post": (None, [vp]), "legion_ipc_client_post_nosync": (None, [vp]), "legion_ipc_client_buffer": (vp, [vp, i32]),
     "legion_ipc_client_steps": (None, [vp, vp]), "legion_ipc_client_hops": (i32, [vp]),
     "legion_ipc_client_read_counters": (None, [vp, vp, vp]), "legion_ipc_client_close": (None, [vp]),
     "NewGPURunner": (vp, []), "Runner_Initialize": (None, [vp, vp]),
@@ -220,6 +225,9 @@ _SIGS = {
     "legion_synth_features_pitched": (None, [vp, vp, i64, i64, i32, i32]),
     "legion_synth_labels": (None, [vp, vp, i32, i32, i32]),
     "legion_synth_seed_ids": (None, [vp, vp, i64, i64, i32, u32, u32, i32, i32]),
+    "legion_synth_spec": (C.c_int, [C.c_char_p, f64, vp]),
+    "legion_synth_label_host": (i32, [i32, i32]),
+    "legion_synth_seed_id_host": (i32, [i64, i32, u32, u32]),
     "legion_copy_f4": (None, [vp, vp, vp, i64]),
     "legion_copy_f4_cfg": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, i32]),
     "legion_rng_probe": (None, [vp, vp, vp, vp, i32]),

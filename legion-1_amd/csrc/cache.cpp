@@ -172,7 +172,7 @@ int32_t* GPUCache_HitSampling(GPUCache* c, int32_t dev_id, int last_launch_of_ba
             int32_t* prev = k->hit_stats + 2 * (slot ^ 1);
             if (k->hit_samples > 0 && prev[1] > 0 && settled(slot ^ 1)) {
                 k->last_hit_rate = (double)prev[0] / (double)prev[1];
-                std::cout << dev_id << " Feature Cache Hit: " << k->last_hit_rate << std::endl;
+                log_out() << dev_id << " Feature Cache Hit: " << k->last_hit_rate << std::endl;
                 prev[1] = 0;   // printed once
             }
             if (settled(slot)) { k->hit_stats[2 * slot] = 0; k->hit_stats[2 * slot + 1] = 0; k->hit_ev_armed[slot] = false; }
@@ -273,7 +273,7 @@ void GPUCache_CandidateSelection(GPUCache* c, int cache_agg_mode, GPUNodeStorage
     const int Kc = c->device_count / Kg;
     c->Kc = Kc;
     c->Kg = Kg;
-    std::cout << "xGMI Clique: " << Kc << " GPU Per Clique: " << Kg << std::endl;
+    log_out() << "xGMI Clique: " << Kc << " GPU Per Clique: " << Kg << std::endl;
     const int32_t V = noder->total_num_nodes;
     for (auto p : c->QF) if (p) (void)hipFree(p);
     for (auto p : c->QT) if (p) (void)hipFree(p);
@@ -412,7 +412,7 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
     const int32_t F = noder->float_attr_len;
     const int Kg = c->Kg, Kc = c->Kc;
     c->node_capacity.clear(); c->edge_capacity.clear(); c->alpha.clear();
-    std::cout << "Start solve cost model" << std::endl;
+    log_out() << "Start solve cost model" << std::endl;
     for (int i = 0; i < Kc; i++) {
         const int home = clique_home(i, Kg);
         if (c->capacity_forced || home < 0) {
@@ -431,7 +431,7 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
             c->node_capacity.push_back(V / Kg + 1);
             c->edge_capacity.push_back(V / Kg + 1);
             c->alpha.push_back((double)h.adjacency_bytes() / (double)budget);
-            std::cout << "Budget covers all data: caching everything\n";
+            log_out() << "Budget covers all data: caching everything\n";
             continue;
         }
         // Feature transactions of the epoch.  The reference sums cache_controller_[j]->MaxIdNum() for j < Kg -- the members
@@ -442,11 +442,11 @@ void GPUCache_CostModel(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, 
         for (int j = 0; j < Kg; j++)
             feat_trans += (uint64_t)(((int64_t)GPUCache_MaxIdNum(c, is_remote_device(j) ? home : j) * train_step * F * (int64_t)sizeof(float)) / CLS);
         const BudgetSplit best = best_split(h, V, F, Kg, budget, topo_trans, feat_trans);
-        std::cout << "Alpha: " << (best.step * MIN_INTERVAL) << " Transactions: " << best.transactions << std::endl;
+        log_out() << "Alpha: " << (best.step * MIN_INTERVAL) << " Transactions: " << best.transactions << std::endl;
         c->node_capacity.push_back((int32_t)(best.feat_rows_per_gpu + 1));
         c->edge_capacity.push_back((int32_t)(best.topo_rows_per_gpu + 1));
         c->alpha.push_back(best.step * MIN_INTERVAL);
-        std::cout << "Feat capacity " << best.feat_rows_per_gpu << " topo capacity " << best.topo_rows_per_gpu << std::endl;
+        log_out() << "Feat capacity " << best.feat_rows_per_gpu << " topo capacity " << best.topo_rows_per_gpu << std::endl;
     }
 }
 
@@ -521,10 +521,10 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
         }
         if (clique_home(i, Kg) >= 0) publish_shard_tables(c, i);
     }
-    std::cout << "Finish load feature cache\n";
+    log_out() << "Finish load feature cache\n";
     for (int i = 0; i < c->Kc; i++)
         if (c->QT[i]) GPUGraphStorage_GraphCache(graph, c->QT[i], i, Kg, c->edge_capacity[i]);
-    std::cout << "Finish load topology cache\n";
+    log_out() << "Finish load topology cache\n";
 }
 
 float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id)

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <iostream>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,11 @@ inline void check(hipError_t e, const char* file, int line)
 #define HIP_CHECK_LAST() ::legion::check(hipGetLastError(), __FILE__, __LINE__)
 #define LEGION_ARG_ERROR(msg) ::legion::report_error(__FILE__, __LINE__, (msg), false)
 
+// Where the library's progress prints go: stdout like the reference's (std::cout / printf all over Server.cu, GPUCache.cu,
+// CUDA_IPC_Service.cu), or stderr under $LEGION_LOG=stderr (read once) -- for a host that owns stdout (bench.py's one JSON line).
+std::ostream& log_out();
+FILE* log_file();
+
 int physical_device(int logical);
 bool is_remote_device(int logical); // logical GPU driven by another process (one process per GPU)
 // RAII: switch to the physical device of a logical id, restore on scope exit
@@ -44,6 +50,11 @@ constexpr uint32_t kProvisional = 0x80000000u; // | slot idx : claimed in the ru
 constexpr int kTile = LEGION_KTILE;            // sampler slots per workgroup tile
 constexpr int kBlock = 256;                    // threads per workgroup
 static_assert(kTile >= kBlock && kTile <= 2048 && (kTile & (kTile - 1)) == 0, "LEGION_KTILE: a power of two in [256, 2048] (k_sample stages 16 bytes of row descriptor per slot in static LDS)");
+// k_mark runs one CONTIGUOUS chunk of tiles per workgroup and leaves the chunk totals in GPUMemoryPool::chunk_tot; k_write scans them in
+// LDS, kMaxChunks / kBlock per thread.  One constant for the allocation (storage.cpp), the grid clamp (launch_sample_hop) and the LDS
+// array (k_write): changing one of them alone would let k_mark write past the allocation.
+constexpr int kMaxChunks = 2048;
+static_assert(kMaxChunks % kBlock == 0 && kMaxChunks >= 256 * 8, "kMaxChunks: a multiple of the workgroup size, >= 256 CUs x 8 workgroups");
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
 constexpr int kMaxParts = LEGION_MAX_DEVICE;
 

@@ -274,15 +274,15 @@ IPCEnv* NewIPCEnv(int32_t device_count)
 {
     if (device_count < 1 || device_count > LEGION_MAX_DEVICE) { LEGION_ARG_ERROR("NewIPCEnv: device_count must be 1..8"); return nullptr; }
     IPCEnv* e = new IPCEnv();
-    std::cout << "start initialize ipc env\n";
+    log_out() << "start initialize ipc env\n";
     e->shm = (volatile shmStruct*)shm_map(sizeof(shmStruct), &e->shm_fd);
     if (!e->shm) {
-        printf("Failed to create shared memory slab\n"); // reference: exit(EXIT_FAILURE) (CUDA_IPC_Service.cu:46-48)
+        fprintf(log_file(), "Failed to create shared memory slab\n"); // reference: exit(EXIT_FAILURE) (CUDA_IPC_Service.cu:46-48)
         delete e;
         LEGION_ARG_ERROR("NewIPCEnv: shm_open/mmap failed");
         return nullptr;
     }
-    std::cout << "Shared Memory Opened\n";
+    log_out() << "Shared Memory Opened\n";
     // $LEGION_IPC_ATTACH=1: another server process of this job already created the slab
     const char* attach = getenv("LEGION_IPC_ATTACH");
     if (!(attach && attach[0] == '1')) memset((void*)e->shm, 0, sizeof(shmStruct));
@@ -328,9 +328,9 @@ void IPCEnv_Coordinate(IPCEnv* e, const LegionBuildInfo* info)
     e->test_step = (max_test_size - 1) / raw_test_batch_size + 1;
     e->test_batch_size.resize(P);
     for (int32_t i = 0; i < P; i++) e->test_batch_size[i] = (info->testing_set_num[i] - 1) / e->test_step + 1;
-    std::cout << "Train Steps: " << e->train_step << "\n";
-    std::cout << "Valid Steps: " << e->valid_step << "\n";
-    std::cout << "Test Steps: " << e->test_step << "\n";
+    log_out() << "Train Steps: " << e->train_step << "\n";
+    log_out() << "Valid Steps: " << e->valid_step << "\n";
+    log_out() << "Test Steps: " << e->test_step << "\n";
     e->shm->steps[0] = e->train_step;
     e->shm->steps[1] = e->valid_step;
     e->shm->steps[2] = e->test_step;
@@ -376,9 +376,9 @@ void IPCEnv_InitializeSamplesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_i
         sem_unlink(ssri.c_str());
         sem_unlink(sswi.c_str());
         e->semr[device_id][i] = sem_open(ssri.c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (e->semr[device_id][i] == SEM_FAILED) { printf("errno = %d\n", errno); return; }
+        if (e->semr[device_id][i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); return; }
         e->semw[device_id][i] = sem_open(sswi.c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (e->semw[device_id][i] == SEM_FAILED) { printf("errno = %d\n", errno); return; }
+        if (e->semw[device_id][i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); return; }
     }
     e->pipeline_depth = pipeline_depth;
 }
@@ -541,7 +541,7 @@ void IPCEnv_Finalize(IPCEnv* e)
             (void)hipFree(e->agg_dst[i][j]);
             (void)hipFree(e->node_counter[i][j]);
             (void)hipFree(e->edge_counter[i][j]);
-            if (e->semw[i][j] && sem_close(e->semw[i][j]) == -1) std::cout << "close sem " << i << " " << j << " failed\n";
+            if (e->semw[i][j] && sem_close(e->semw[i][j]) == -1) log_out() << "close sem " << i << " " << j << " failed\n";
             if (e->semr[i][j]) sem_close(e->semr[i][j]);
             sem_unlink(sem_name("r", i, (int)j).c_str());
             sem_unlink(sem_name("w", i, (int)j).c_str());
@@ -652,7 +652,7 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
     // e.g. several logical GPUs of a clique exercised on one physical device
     if (device_id < 0 && getenv("LEGION_IPC_DEVICE")) c->device = atoi(getenv("LEGION_IPC_DEVICE"));
     c->shm = (volatile shmStruct*)shm_map(sizeof(shmStruct), &c->shm_fd);
-    if (!c->shm) { printf("Failed to create shared memory slab\n"); delete c; LEGION_ARG_ERROR("legion_ipc_client_open: shm"); return nullptr; }
+    if (!c->shm) { fprintf(log_file(), "Failed to create shared memory slab\n"); delete c; LEGION_ARG_ERROR("legion_ipc_client_open: shm"); return nullptr; }
     for (int i = 0; i < 3; i++) c->steps[i] = c->shm->steps[i];
     c->hops = c->shm->ext_hops > 0 ? c->shm->ext_hops : 2;
     if (c->device >= LEGION_MAX_DEVICE) { LEGION_ARG_ERROR("legion_ipc_client_open: device id >= 8"); delete c; return nullptr; }
@@ -673,12 +673,12 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
             HIP_CHECK(hipIpcOpenMemHandle(&c->buf[i][w], h, hipIpcMemLazyEnablePeerAccess));
         }
     }
-    std::cout << "HIP: " << c->device << " IPC shared memory opened\n";
+    log_out() << "HIP: " << c->device << " IPC shared memory opened\n";
     for (int i = 0; i < LEGION_PIPELINE_DEPTH; i++) {
         c->semr[i] = sem_open(sem_name("r", c->device, i).c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (c->semr[i] == SEM_FAILED) { printf("errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); return c; }
+        if (c->semr[i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); return c; }
         c->semw[i] = sem_open(sem_name("w", c->device, i).c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (c->semw[i] == SEM_FAILED) { printf("errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); return c; }
+        if (c->semw[i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); return c; }
         sem_post(c->semr[i]); // both pipes start free (ipc_cuda_kernel.cu:91)
     }
     c->current_pipe = 0;
@@ -689,7 +689,19 @@ void legion_ipc_client_wait(LegionIPCClient* c)
 {
     while (sem_wait(c->semw[c->current_pipe]) != 0 && errno == EINTR) {}
 }
+// Post(): the pipe's buffers go back to the server, which overwrites them with batch i + 2.  The reference's trainer never
+// synchronises its device around synchronize() (legion_graphsage.py:93-116): what bounded its run-ahead was the BLOCKING counter copy of
+// the next get_next (ipc_cuda_kernel.cu:195-196, legacy default stream: waits for everything the trainer has queued).  Here get_next reads
+// the host mirror and synchronises nothing, so the wait moves to where it is needed: everything this process has queued on its device --
+// kernels still reading the batch's ids / rows / COO -- completes BEFORE the semaphore is posted.  One device synchronisation per batch,
+// as in the reference, and the pipe is really free when the server sees it.
 void legion_ipc_client_post(LegionIPCClient* c)
+{
+    HIP_CHECK(hipDeviceSynchronize());
+    legion_ipc_client_post_nosync(c);
+}
+// ... for a consumer that has already waited for its own work (an event / stream synchronisation of its own, or no device work at all)
+void legion_ipc_client_post_nosync(LegionIPCClient* c)
 {
     sem_post(c->semr[c->current_pipe]);
     c->current_pipe = (c->current_pipe + 1) % LEGION_PIPELINE_DEPTH;
@@ -729,7 +741,7 @@ void legion_ipc_client_close(LegionIPCClient* c)
                 (void)hipIpcCloseMemHandle(c->buf[i][w]);
             }
         }
-        if (c->semw[i] && c->semw[i] != SEM_FAILED && sem_close(c->semw[i]) == -1) std::cout << "close sem " << i << " failed\n";
+        if (c->semw[i] && c->semw[i] != SEM_FAILED && sem_close(c->semw[i]) == -1) log_out() << "close sem " << i << " failed\n";
         if (c->semr[i] && c->semr[i] != SEM_FAILED) sem_close(c->semr[i]);
     }
     if (c->shm) { munmap((void*)c->shm, sizeof(shmStruct)); close(c->shm_fd); }

@@ -342,7 +342,7 @@ __device__ inline int32_t win_rank(int32_t v) { return -2 - v - kWinBase; }
 // its tiles INSIDE its chunk (tile_pre) and the chunk's totals (chunk_tot); k_write scans the <= kMaxChunks chunk totals in LDS (8-16 KB of
 // shared reads per workgroup instead of every tile count: 35-70 KB at 4-9 k tiles, re-read by all 1536 workgroups at once -- one such prefix
 // build cost 6.8 / 16.3 us per launch at the papers100M / products hop 3, profiles/r04_sampler.md) and adds tile_pre[t] of any tile it needs.
-constexpr int kMaxChunks = 2048;   // >= the largest k_mark grid (256 CUs x 8 workgroups)
+// kMaxChunks (internal.h) >= the largest k_mark grid (256 CUs x 8 workgroups); GPUMemoryPool_AllocateScratch sizes chunk_tot with it.
 __host__ __device__ inline FastDiv make_fastdiv(uint32_t div)
 {
     FastDiv f;
@@ -490,6 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
     __shared__ int2 s_chunk[kMaxChunks];
     __shared__ int32_t s_e[S * W];
     __shared__ int2 s_scan[W];
+    __shared__ uint32_t s_div_t[3];
     const HopState h = *a.hs;
     const uint32_t epoch = a.ctl->epoch;
     const int32_t total = h.slots;
@@ -502,7 +503,10 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
     }
     if ((int32_t)blockIdx.x >= n_tiles) return;
     const int32_t T = (n_tiles + a.mark_grid - 1) / a.mark_grid;   // tiles per chunk, as k_mark derived it
-    const FastDiv div_t = make_fastdiv((uint32_t)T);
+    if (threadIdx.x == 0) {                                        // one 64-bit divide per workgroup (T is device-side: no host round trip)
+        const FastDiv f = make_fastdiv((uint32_t)T);
+        s_div_t[0] = f.d; s_div_t[1] = f.m; s_div_t[2] = f.s;
+    }
     const int32_t n_chunks = (n_tiles + T - 1) / T;                // <= mark_grid <= kMaxChunks
     {
         constexpr int PER = kMaxChunks / kBlock;                    // consecutive chunks per thread
@@ -534,6 +538,8 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
         }
         __syncthreads();
     }
+    FastDiv div_t;
+    div_t.d = s_div_t[0]; div_t.m = s_div_t[1]; div_t.s = s_div_t[2];
     // new nodes in front of tile t (what an edge that lost its claim needs of its winner's tile); `pre` = tile_pre[t]
     auto nodes_before = [&](int32_t t, int32_t pre_n_in_chunk) { return s_chunk[fdiv((uint32_t)t, div_t)].y + pre_n_in_chunk; };
 

@@ -52,10 +52,10 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
         all_labels = GPUNodeStorage_GetTestingLabels(noder, dev_id);
         total_cap = GPUNodeStorage_TestingSetSize(noder, dev_id);
     } else {
-        std::cout << "invalid mode: " << mode << "\n";
+        log_out() << "invalid mode: " << mode << "\n";
     }
-    if (all_ids == nullptr) { std::cout << "invalid src id ptr\n"; return; }
-    if (all_labels == nullptr) { std::cout << "invalid label ptr\n"; return; }
+    if (all_ids == nullptr) { log_out() << "invalid src id ptr\n"; return; }
+    if (all_labels == nullptr) { log_out() << "invalid label ptr\n"; return; }
 
     GPUMemoryPool* p = memorypool;
     p->device_id = dev_id;
@@ -93,7 +93,7 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
 void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache, GPUMemoryPool* memorypool,
                          int32_t count, int32_t op_id, int is_presc)
 {
-    if (graph == nullptr) { std::cout << "invalid storage ptr\n"; return; }
+    if (graph == nullptr) { log_out() << "invalid storage ptr\n"; return; }
     if (!pool_ready(memorypool, "GPU_Random_Sampling")) return;
     GPUMemoryPool* p = memorypool;
     const int hop = op_id / 2;
@@ -152,7 +152,7 @@ static bool gather_args(GatherArgs& g, GPUCache* cache, GPUNodeStorage* noder, G
                         bool count_hits = true)
 {
     const int32_t F = noder->float_attr_len;
-    if (F < 0) std::cout << "error feature len\n"; // Kernels.cu:719-721
+    if (F < 0) log_out() << "error feature len\n"; // Kernels.cu:719-721
     const int q = p->current_pipe;
     if (!p->float_features[q]) { LEGION_ARG_ERROR("get_feature_kernel: feature buffer of the current pipe is not set"); return false; }
     const bool replica = dev_id >= 0 && dev_id < noder->partition_count && noder->replica_attrs[dev_id];

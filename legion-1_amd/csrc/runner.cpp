@@ -259,7 +259,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     if (error_pending()) {
         // an operator refused its arguments (sticky error): the buffers of this pipe hold stale data.  Never hand
         // them to a trainer -- the reference's error behaviour is exit(EXIT_FAILURE) (Kernels.cuh:14-22).
-        std::cout << "Runner_RunOnce: batch " << batch_id << " on GPU " << r->local_dev_id << " failed; server stops\n" << std::flush;
+        log_out() << "Runner_RunOnce: batch " << batch_id << " on GPU " << r->local_dev_id << " failed; server stops\n" << std::flush;
         if (error_is_fatal()) exit(EXIT_FAILURE);
         post_poisoned();
         return;
@@ -320,7 +320,7 @@ bool read_file(const std::string& path, void* dst, int64_t max_bytes, int64_t* g
 {
     int fd = open(path.c_str(), O_RDONLY);
     if (fd == -1) {
-        if (!quiet) std::cout << "cannout open file: " << path << "\n";
+        if (!quiet) log_out() << "cannout open file: " << path << "\n";
         return false;
     }
     struct stat st;
@@ -361,7 +361,85 @@ struct Server {
     int64_t* indptr = nullptr;
     int32_t* indices = nullptr;
     float* feats = nullptr;
+    bool synth = false;        // the tables were generated in HBM (dataset source `synth:`), not read into pinned host memory
+    int32_t synth_pitch = 0;   // floats between two feature rows of the generated tables
 };
+
+namespace {
+
+// One copy of the synthetic tables on the CURRENT device: degrees -> in-place scan -> indptr, neighbours, features.
+bool synth_tables_here(const LegionSynthSpec& sp, int32_t skew, int32_t pitch, int64_t** indptr, int32_t** indices, float** feats, int64_t* E)
+{
+    const int32_t V = sp.V;
+    HIP_CHECK(hipMalloc(indptr, ((size_t)V + 1) * sizeof(int64_t)));
+    if (!*indptr) return false;
+    HIP_CHECK(hipMemset(*indptr, 0, sizeof(int64_t)));
+    legion_synth_degrees(nullptr, *indptr + 1, 0, V, sp.ladder);
+    inclusive_scan_i64(nullptr, *indptr + 1, *indptr + 1, V);
+    HIP_CHECK(hipMemcpy(E, *indptr + V, sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMalloc(indices, (size_t)std::max<int64_t>(*E, 1) * sizeof(int32_t)));
+    if (!*indices) return false;
+    legion_synth_neighbors_skew(nullptr, *indices, 0, *E, V, sp.M, sp.C, skew);
+    HIP_CHECK(hipMalloc(feats, (size_t)V * pitch * sizeof(float)));
+    if (!*feats) return false;
+    if (pitch > sp.F) HIP_CHECK(hipMemset(*feats, 0, (size_t)V * pitch * sizeof(float)));
+    legion_synth_features_pitched(nullptr, *feats, 0, V, sp.F, pitch);
+    HIP_CHECK(hipDeviceSynchronize());
+    return !error_pending();
+}
+
+int32_t synth_skew(const std::string& path)
+{
+    const size_t c1 = path.find(':', 6);
+    const size_t c2 = c1 == std::string::npos ? c1 : path.find(':', c1 + 1);
+    return c2 == std::string::npos ? 205 : atoi(path.substr(c2 + 1).c_str());
+}
+
+// `synth:<workload>[:<scale>[:<skew>]]`: parse, check the meta line against the generator, generate on logical GPU 0.
+bool load_synth(Server* s, int G, LegionSynthSpec& spec)
+{
+    Meta& m = s->meta;
+    std::string rest = m.dataset_path.substr(6), name = rest;
+    double scale = 1.0;
+    int32_t skew = 205;
+    const size_t c1 = rest.find(':');
+    if (c1 != std::string::npos) {
+        name = rest.substr(0, c1);
+        const std::string tail = rest.substr(c1 + 1);
+        const size_t c2 = tail.find(':');
+        scale = atof(tail.substr(0, c2).c_str());
+        if (c2 != std::string::npos) skew = atoi(tail.substr(c2 + 1).c_str());
+    }
+    if (legion_synth_spec(name.c_str(), scale, &spec) != 0) { LEGION_ARG_ERROR("Server_Initialize: the synth: dataset path names no known workload / scale"); return false; }
+    if (spec.V != m.node_num || spec.F != m.float_attr_len || skew < 0 || skew > 256) {
+        LEGION_ARG_ERROR("Server_Initialize: node count / feature dim of the meta line differ from the synth: generator's");
+        return false;
+    }
+    if (m.training_set_num > spec.n_train || m.validation_set_num > spec.n_valid || m.testing_set_num > spec.n_test ||
+        m.training_set_num < 0 || m.validation_set_num < 0 || m.testing_set_num < 0) {
+        LEGION_ARG_ERROR("Server_Initialize: a seed set of the meta line is larger than the synth: generator's");
+        return false;
+    }
+    log_out() << "Start generate graph (" << name << ", scale " << scale << ", skew " << skew << "/256)\n";
+    s->synth = true;
+    s->synth_pitch = legion_row_pitch(spec.F);
+    (void)G;
+    DeviceGuard guard(0);
+    int64_t E = 0;
+    if (!synth_tables_here(spec, skew, s->synth_pitch, &s->indptr, &s->indices, &s->feats, &E)) {
+        LEGION_ARG_ERROR("Server_Initialize: generating the synth: tables failed");
+        return false;
+    }
+    if (m.edge_num != 0 && m.edge_num != E) {
+        LEGION_ARG_ERROR("Server_Initialize: edge count of the meta line differs from the synth: generator's");
+        return false;
+    }
+    m.edge_num = E;
+    log_out() << "Graph generated in HBM: " << E << " edges\n";
+    return true;
+}
+
+} // namespace
 
 extern "C" {
 
@@ -379,17 +457,17 @@ void Server_Initialize(Server* s, int global_shard_count)
     if (!s || global_shard_count < 1 || global_shard_count > kMaxParts) { LEGION_ARG_ERROR("Server_Initialize: shard count must be 1..8"); return; }
     const int G = global_shard_count;
     s->shard_count = G;
-    std::cout << "HIP Device Count: " << G << "\n";
+    log_out() << "HIP Device Count: " << G << "\n";
     Meta& m = s->meta;
     {
         std::ifstream f(s->meta_path);
-        if (!f.is_open()) { std::cout << "unable to open meta config file\n"; LEGION_ARG_ERROR("Server_Initialize: meta_config missing"); return; }
+        if (!f.is_open()) { log_out() << "unable to open meta config file\n"; LEGION_ARG_ERROR("Server_Initialize: meta_config missing"); return; }
         std::string line;
         getline(f, line);
         std::istringstream iss(line);
         iss >> m.dataset_path >> m.raw_batch_size >> m.node_num >> m.edge_num >> m.float_attr_len >> m.training_set_num >>
             m.validation_set_num >> m.testing_set_num >> m.cache_memory >> m.epoch >> m.partition;
-        std::cout << "Dataset path:       " << m.dataset_path << "\nRaw Batchsize:      " << m.raw_batch_size
+        log_out() << "Dataset path:       " << m.dataset_path << "\nRaw Batchsize:      " << m.raw_batch_size
                   << "\nGraph nodes num:    " << m.node_num << "\nGraph edges num:    " << m.edge_num
                   << "\nFeature dim:        " << m.float_attr_len << "\nTraining set num:   " << m.training_set_num
                   << "\nValidation set num: " << m.validation_set_num << "\nTesting set num:    " << m.testing_set_num
@@ -398,25 +476,43 @@ void Server_Initialize(Server* s, int global_shard_count)
     }
     const int32_t V = m.node_num;
     const int32_t F = m.float_attr_len;
+    std::vector<int32_t> training_ids, validation_ids, testing_ids, all_labels, partition_index;
+    bool have_part = false;
+    const bool synth = m.dataset_path.rfind("synth:", 0) == 0;
+    LegionSynthSpec spec;
+    if (synth) {
+        // Dataset source `synth:<workload>[:<scale>[:<skew>]]` (extension): the tables of the named synthetic shape are generated
+        // on the device by the legion_synth_* calls bench.py uses -- 64 GB of files per start is not an option for the papers100M
+        // shape.  V, E, F of the meta line must be the generator's (E = 0: not checked); the seed-set sizes of the meta line take
+        // the first n ids of the generator's train / valid / test ranges.
+        if (!load_synth(s, G, spec)) return;
+        training_ids.resize(m.training_set_num); validation_ids.resize(m.validation_set_num); testing_ids.resize(m.testing_set_num);
+        for (int32_t i = 0; i < m.training_set_num; i++) training_ids[i] = legion_synth_seed_id_host(i, V, spec.M2, spec.C2);
+        for (int32_t i = 0; i < m.validation_set_num; i++) validation_ids[i] = legion_synth_seed_id_host((int64_t)spec.n_train + i, V, spec.M2, spec.C2);
+        for (int32_t i = 0; i < m.testing_set_num; i++) testing_ids[i] = legion_synth_seed_id_host((int64_t)spec.n_train + spec.n_valid + i, V, spec.M2, spec.C2);
+        if (m.partition == 2) { LEGION_ARG_ERROR("Server_Initialize: a synth: dataset has no pre-partitioned training lists (meta flag 2)"); return; }
+    } else {
     // Load_Graph / Load_Feature (GPUGraphStore.cu:254-325): pinned, device-mapped host memory
-    std::cout << "Start load graph\n";
+    log_out() << "Start load graph\n";
     s->indptr = (int64_t*)host_alloc_space64(((int64_t)V + 1) * 8);
     s->indices = (int32_t*)host_alloc_space64(m.edge_num * 4);
     bool ok = read_file(m.dataset_path + "edge_src", s->indptr, ((int64_t)V + 1) * 8);
     ok = read_file(m.dataset_path + "edge_dst", s->indices, m.edge_num * 4) && ok;
-    std::cout << "start load node\n";
+    log_out() << "start load node\n";
     s->feats = (float*)host_alloc_space64((int64_t)V * F * 4);
     ok = read_file(m.dataset_path + "features", s->feats, (int64_t)V * F * 4) && ok;
-    std::vector<int32_t> training_ids(m.training_set_num), validation_ids(m.validation_set_num), testing_ids(m.testing_set_num),
-        all_labels(V), partition_index(V);
+    training_ids.resize(m.training_set_num); validation_ids.resize(m.validation_set_num); testing_ids.resize(m.testing_set_num);
+    all_labels.resize(V); partition_index.resize(V);
     ok = read_file(m.dataset_path + "trainingset", training_ids.data(), (int64_t)m.training_set_num * 4) && ok;
     ok = read_file(m.dataset_path + "validationset", validation_ids.data(), (int64_t)m.validation_set_num * 4) && ok;
     ok = read_file(m.dataset_path + "testingset", testing_ids.data(), (int64_t)m.testing_set_num * 4) && ok;
     ok = read_file(m.dataset_path + "labels", all_labels.data(), (int64_t)V * 4) && ok;
     // the reference only prints "cannout open file" and carries on with garbage (GPUGraphStore.cu:33-35); fail instead
     if (!ok) { LEGION_ARG_ERROR("Server_Initialize: dataset file(s) missing"); return; }
-    const bool have_part = read_file(m.dataset_path + "partition_" + std::to_string(G) + "_bn", partition_index.data(), (int64_t)V * 4, nullptr, true);
-    std::cout << "Finish Reading All Files\n";
+    have_part = read_file(m.dataset_path + "partition_" + std::to_string(G) + "_bn", partition_index.data(), (int64_t)V * 4, nullptr, true);
+    }
+    auto label_of = [&](int32_t id) { return synth ? legion_synth_label_host(id, spec.classes) : all_labels[id]; };
+    log_out() << "Finish Reading All Files\n";
     // seed split, GPUGraphStore.cu:332-414
     s->tr_ids.assign(G, {}); s->va_ids.assign(G, {}); s->te_ids.assign(G, {});
     s->tr_lab.assign(G, {}); s->va_lab.assign(G, {}); s->te_lab.assign(G, {});
@@ -424,10 +520,11 @@ void Server_Initialize(Server* s, int global_shard_count)
         // Pre-partitioned training lists (extension, not in the reference): meta flag 2 = GPU g serves the file
         // trainingset_<G>_<g> verbatim.  Needed for link prediction on G > 1 GPUs: lp_sage.py:87-90 expects every
         // batch as [src | pos | neg] thirds, which neither split rule below preserves (synth.lp_trainingset writes them).
+        bool ok = true;
         for (int g = 0; g < G && ok; g++) {
             const std::string path = m.dataset_path + "trainingset_" + std::to_string(G) + "_" + std::to_string(g);
             struct stat st;
-            if (stat(path.c_str(), &st) != 0) { std::cout << "cannout open file: " << path << "\n"; ok = false; break; }
+            if (stat(path.c_str(), &st) != 0) { log_out() << "cannout open file: " << path << "\n"; ok = false; break; }
             s->tr_ids[g].resize((size_t)st.st_size / 4);
             ok = read_file(path, s->tr_ids[g].data(), (int64_t)s->tr_ids[g].size() * 4);
             for (int32_t tid : s->tr_ids[g]) if (tid < 0 || tid >= V) ok = false;
@@ -445,14 +542,14 @@ void Server_Initialize(Server* s, int global_shard_count)
     std::vector<int32_t> tn(G), vn(G), en(G);
     std::vector<const int32_t*> tp(G), vp(G), ep(G), tlp(G), vlp(G), elp(G);
     for (int p = 0; p < G; p++) {
-        for (int32_t id : s->tr_ids[p]) s->tr_lab[p].push_back(all_labels[id]);
-        for (int32_t id : s->va_ids[p]) s->va_lab[p].push_back(all_labels[id]);
-        for (int32_t id : s->te_ids[p]) s->te_lab[p].push_back(all_labels[id]);
+        for (int32_t id : s->tr_ids[p]) s->tr_lab[p].push_back(label_of(id));
+        for (int32_t id : s->va_ids[p]) s->va_lab[p].push_back(label_of(id));
+        for (int32_t id : s->te_ids[p]) s->te_lab[p].push_back(label_of(id));
         tn[p] = (int32_t)s->tr_ids[p].size(); vn[p] = (int32_t)s->va_ids[p].size(); en[p] = (int32_t)s->te_ids[p].size();
         tp[p] = s->tr_ids[p].data(); vp[p] = s->va_ids[p].data(); ep[p] = s->te_ids[p].data();
         tlp[p] = s->tr_lab[p].data(); vlp[p] = s->va_lab[p].data(); elp[p] = s->te_lab[p].data();
     }
-    std::cout << "Finish Partition\n";
+    log_out() << "Finish Partition\n";
     LegionBuildInfo info;
     memset(&info, 0, sizeof(info));
     info.partition_count = G;
@@ -460,8 +557,10 @@ void Server_Initialize(Server* s, int global_shard_count)
     info.validation_set_num = vn.data(); info.validation_set_ids = vp.data(); info.validation_labels = vlp.data();
     info.testing_set_num = en.data(); info.testing_set_ids = ep.data(); info.testing_labels = elp.data();
     info.total_num_nodes = V; info.float_attr_len = F;
-    info.host_float_attrs = s->feats; info.features_location = LEGION_LOC_HOST_PINNED;
-    info.csr_node_index = s->indptr; info.csr_dst_node_ids = s->indices; info.csr_location = LEGION_LOC_HOST_PINNED;
+    const int32_t table_loc = synth ? LEGION_LOC_DEVICE : LEGION_LOC_HOST_PINNED;
+    info.host_float_attrs = s->feats; info.features_location = table_loc;
+    info.float_attr_pitch = synth ? s->synth_pitch : 0;
+    info.csr_node_index = s->indptr; info.csr_dst_node_ids = s->indices; info.csr_location = table_loc;
     info.total_edge_num = m.edge_num; info.cache_edge_num = 0;
     info.epoch = m.epoch; info.raw_batch_size = m.raw_batch_size;
 
@@ -476,7 +575,7 @@ void Server_Initialize(Server* s, int global_shard_count)
     // (default auto: replicate when CSR + features + 20 % fit into the free HBM of every GPU).
     {
         const char* mode = getenv("LEGION_TABLES");
-        const std::string tables = mode ? mode : "auto";
+        const std::string tables = synth ? "synth" : (mode ? mode : "auto");
         const int64_t need = (((int64_t)V + 1) * 8 + m.edge_num * 4 + (int64_t)V * F * 4);
         bool replicate = tables == "device";
         if (tables == "auto") {
@@ -488,19 +587,44 @@ void Server_Initialize(Server* s, int global_shard_count)
                 if ((double)need * 1.2 > (double)free_b) replicate = false;
             }
         }
-        if (replicate) {
+        if (synth) {
+            // generated in HBM on logical GPU 0; every other physical device of the job gets a copy of its own, generated in place
+            // (the storages free them as replicas)
+            std::vector<int> have{physical_device(0)};
+            for (int i = 1; i < G; i++) {
+                const int phys = physical_device(i);
+                int src = -1;
+                for (int j = 1; j < i; j++) if (physical_device(j) == phys && s->graph->replica_indptr[j]) src = j;
+                if (phys == have[0]) continue;                         // shares GPU 0's tables
+                if (src >= 0) {
+                    s->graph->replica_indptr[i] = s->graph->replica_indptr[src]; s->graph->replica_indices[i] = s->graph->replica_indices[src];
+                    s->noder->replica_attrs[i] = s->noder->replica_attrs[src];
+                    continue;
+                }
+                DeviceGuard guard(i);
+                int64_t E2 = 0;
+                if (!synth_tables_here(spec, synth_skew(m.dataset_path), s->synth_pitch, &s->graph->replica_indptr[i], &s->graph->replica_indices[i],
+                                       &s->noder->replica_attrs[i], &E2) || E2 != m.edge_num) {
+                    LEGION_ARG_ERROR("Server_Initialize: generating the synth: tables on a further GPU failed");
+                    return;
+                }
+            }
+            s->noder->replica_pitch = s->synth_pitch;
+            s->replicated = true;
+            log_out() << "Tables generated in HBM: " << need / 1e9 << " GB per GPU\n";
+        } else if (replicate) {
             GPUGraphStorage_ReplicateToDevices(s->graph);
             GPUNodeStorage_ReplicateToDevices(s->noder);
             s->replicated = true;
-            std::cout << "Tables replicated into HBM: " << need / 1e9 << " GB per GPU\n";
+            log_out() << "Tables replicated into HBM: " << need / 1e9 << " GB per GPU\n";
         } else {
-            std::cout << "Tables stay in pinned host memory (" << need / 1e9 << " GB)\n";
+            log_out() << "Tables stay in pinned host memory (" << need / 1e9 << " GB)\n";
         }
     }
     s->cache = NewGPUCache();
     const int32_t train_step = IPCEnv_GetTrainStep(s->env);
     GPUCache_Initialize(s->cache, m.cache_memory, 0, F, train_step, G);
-    std::cout << "Storage Initialized\n";
+    log_out() << "Storage Initialized\n";
     s->train_step = train_step;
     s->max_step = IPCEnv_GetMaxStep(s->env);
     s->runners.resize(G);
@@ -539,8 +663,8 @@ void Server_PreSc(Server* s, int cache_agg_mode)
     if (s->replicated) GPUCache_SetCapacity(s->cache, 0, 0);
     GPUCache_CostModel(s->cache, cache_agg_mode, s->noder, s->graph, nullptr, s->train_step);
     GPUCache_FillUp(s->cache, cache_agg_mode, s->noder, s->graph);
-    std::cout << "First epoch cost: " << t << " s\n";
-    std::cout << "System is ready for serving\n" << std::flush;
+    log_out() << "First epoch cost: " << t << " s\n";
+    log_out() << "System is ready for serving\n" << std::flush;
 }
 
 // Run, Server.cu:116-135
@@ -563,13 +687,13 @@ void Server_Finalize(Server* s)
     for (int i = 0; i < s->shard_count; i++) {
         int64_t st[3];
         legion_peer_exchange_stats(Runner_GetMemoryPool(s->runners[i]), st);     // $LEGION_PEER_GATHER=exchange: what the bulk-copy gather did
-        if (st[0] > 0) std::cout << i << " peer exchange gather: " << st[0] << " batches, " << st[1] << " rows over hipMemcpyPeerAsync, " << st[2] << " host syncs\n";
+        if (st[0] > 0) log_out() << i << " peer exchange gather: " << st[0] << " batches, " << st[1] << " rows over hipMemcpyPeerAsync, " << st[2] << " host syncs\n";
         Runner_Finalize(s->runners[i], s->params[i]);
     }
     GPUGraphStorage_Finalize(s->graph);
     GPUNodeStorage_Finalize(s->noder);
     IPCEnv_Finalize(s->env);
-    std::cout << "Server Stopped\n";
+    log_out() << "Server Stopped\n";
 }
 
 void Server_Delete(Server* s)
@@ -580,9 +704,14 @@ void Server_Delete(Server* s)
     if (s->cache) GPUCache_Delete(s->cache);
     if (s->graph) GPUGraphStorage_Delete(s->graph);
     if (s->noder) GPUNodeStorage_Delete(s->noder);
-    if (s->indptr) host_free_space(s->indptr);
-    if (s->indices) host_free_space(s->indices);
-    if (s->feats) host_free_space(s->feats);
+    if (s->synth) {
+        DeviceGuard guard(0);
+        (void)hipFree(s->indptr); (void)hipFree(s->indices); (void)hipFree(s->feats);
+    } else {
+        if (s->indptr) host_free_space(s->indptr);
+        if (s->indices) host_free_space(s->indices);
+        if (s->feats) host_free_space(s->feats);
+    }
     delete s;
 }
 

@@ -20,14 +20,22 @@ void report_error(const char* file, int line, const char* msg, bool hip_failure)
     // reference text: "Cuda failure %s:%d: '%s'" (Kernels.cuh:18)
     snprintf(buf, sizeof(buf), "%s failure %s:%d: '%s'", hip_failure ? "Hip" : "Legion", file, line, msg);
     if (hip_failure && g_error_mode == LEGION_ERR_EXIT) {
-        printf("%s\n", buf);
-        fflush(stdout);
+        fprintf(log_file(), "%s\n", buf);
+        fflush(log_file());
         exit(EXIT_FAILURE);
     }
     if (t_last_error.empty()) t_last_error = buf; // sticky: first error wins
     if (!hip_failure && g_error_mode == LEGION_ERR_EXIT) fprintf(stderr, "%s\n", buf);
     (void)hipGetLastError(); // clear HIP's own sticky flag so later calls are attributable
 }
+
+static int log_to_stderr()
+{
+    static const int v = [] { const char* e = getenv("LEGION_LOG"); return (e && strcmp(e, "stderr") == 0) ? 1 : 0; }();
+    return v;
+}
+std::ostream& log_out() { return log_to_stderr() ? std::cerr : std::cout; }
+FILE* log_file() { return log_to_stderr() ? stderr : stdout; }
 
 bool error_pending() { return !t_last_error.empty(); }
 bool error_is_fatal() { return g_error_mode == LEGION_ERR_EXIT; }

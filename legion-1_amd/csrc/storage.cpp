@@ -569,7 +569,7 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     HIP_CHECK(hipMalloc(&p->tile_edge, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_node, (size_t)(p->max_tiles + 1) * sizeof(int32_t)));
     HIP_CHECK(hipMalloc(&p->tile_pre, (size_t)(p->max_tiles + 1) * sizeof(int2)));
-    HIP_CHECK(hipMalloc(&p->chunk_tot, (size_t)2048 * sizeof(int2)));   // kMaxChunks (kernels.hip)
+    HIP_CHECK(hipMalloc(&p->chunk_tot, (size_t)kMaxChunks * sizeof(int2)));
     HIP_CHECK(hipMalloc(&p->hop_state, sizeof(HopState)));
     HIP_CHECK(hipMalloc(&p->cache_search_buffer, (size_t)p->num_ids * sizeof(int32_t)));
     HIP_CHECK(hipMalloc((void**)&p->row_ptr, (size_t)p->num_ids * sizeof(float*)));

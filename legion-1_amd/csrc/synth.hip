@@ -3,6 +3,8 @@
 // the streaming copy used by bench.py to report the measured HBM peak.
 #include "internal.h"
 #include <algorithm>
+#include <cmath>
+#include <cstring>
 
 namespace legion {
 
@@ -185,6 +187,80 @@ void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int3
     k_synth_labels<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(out, v0, n, classes);
     HIP_CHECK_LAST();
 }
+// ---- the generator's parameters (host; the C statement of legion-1_amd/synth.py spec_for / SynthSpec / degree_ladder) --------------
+// Everything a `synth:` dataset source (runner.cpp, Server_Initialize) needs to regenerate, on the device, exactly the graph that
+// synth.py / bench.py build from the same (workload, scale): tests/test_host_logic.py compares every field with the Python spec.
+namespace {
+struct Shape { const char* name; int64_t V, E; int32_t F, n_train, n_valid, n_test, classes; };
+// legion_server.py:6-37 (V, E, F, seed-set sizes); classes as in synth.py SHAPES
+const Shape kShapes[] = {
+    {"products", 2449029, 123718280, 100, 196615, 39323, 2213091, 47},
+    {"papers100M", 111059956, 1615685872, 128, 11105995, 100000, 100000, 172},
+    {"uk-union", 133633040, 5507679822, 256, 13363304, 100000, 100000, 172},
+};
+uint64_t gcd_u64(uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; }
+uint32_t coprime_multiplier(uint64_t V, uint64_t start)
+{
+    uint64_t m = start % V;
+    if (m < 2) m = V > 2 ? 2 : 1;
+    while (gcd_u64(m, V) != 1) m++;
+    return (uint32_t)m;
+}
+// degree_ladder(): lo[b] = d0 * 1.6^b rounded half-to-even (Python's round), made strictly increasing; d0 by 80 bisection steps on
+// the expected degree.  Plain IEEE double arithmetic in the order synth.py writes it; no fused multiply-add.
+#pragma clang fp contract(off)
+void ladder_of(double d0, int32_t lo[NBUCKET + 2])
+{
+    for (int b = 0; b < NBUCKET + 2; b++) {
+        const double r = nearbyint(d0 * pow(1.6, (double)b));
+        lo[b] = r < 1.0 ? 1 : (int32_t)r;
+    }
+    for (int b = 1; b < NBUCKET + 2; b++) if (lo[b] < lo[b - 1] + 1) lo[b] = lo[b - 1] + 1;
+}
+double ladder_mean(const int32_t lo[NBUCKET + 2])
+{
+    double m = 0.0;
+    for (int b = 0; b < NBUCKET + 1; b++) {
+        const double p = b < NBUCKET ? ldexp(1.0, -(b + 1)) : ldexp(1.0, -NBUCKET);
+        m += p * ((double)lo[b] + (double)(lo[b + 1] - lo[b] - 1) / 2.0);
+    }
+    return m;
+}
+} // namespace
+
+int legion_synth_spec(const char* workload, double scale, LegionSynthSpec* out)
+{
+    if (!workload || !out || !(scale > 0.0) || scale > 1.0) { LEGION_ARG_ERROR("legion_synth_spec: workload name and 0 < scale <= 1 expected"); return -1; }
+    const Shape* sh = nullptr;
+    for (const Shape& s : kShapes) if (strcmp(s.name, workload) == 0) sh = &s;
+    if (!sh) { LEGION_ARG_ERROR("legion_synth_spec: unknown workload (products | papers100M | uk-union)"); return -1; }
+    memset(out, 0, sizeof(*out));
+    int64_t V = sh->V, n_train = sh->n_train, n_valid = sh->n_valid, n_test = sh->n_test;
+    if (scale != 1.0) {                     // synth.py spec_for: V and the seed sets shrink, the mean degree stays
+        V = std::max<int64_t>(64, (int64_t)((double)sh->V * scale));
+        n_train = std::max<int64_t>(1, (int64_t)((double)sh->n_train * scale));
+        n_valid = std::max<int64_t>(1, (int64_t)((double)sh->n_valid * scale));
+        n_test = std::max<int64_t>(1, (int64_t)((double)sh->n_test * scale));
+        if (n_train + n_valid + n_test > V) n_test = std::max<int64_t>(1, V - n_train - n_valid);
+    }
+    out->V = (int32_t)V; out->F = sh->F; out->classes = sh->classes;
+    out->n_train = (int32_t)n_train; out->n_valid = (int32_t)n_valid; out->n_test = (int32_t)n_test;
+    out->mean_degree = (double)sh->E / (double)sh->V;
+    out->M = coprime_multiplier((uint64_t)V, 0x9E3779B1ull);  out->C = (uint32_t)(0x7F4A7C15ull % (uint64_t)V);
+    out->M2 = coprime_multiplier((uint64_t)V, 0x85EBCA6Bull); out->C2 = (uint32_t)(0xC2B2AE35ull % (uint64_t)V);
+    double a = 0.01, b = 1e4;
+    int32_t lo[NBUCKET + 2];
+    for (int it = 0; it < 80; it++) {
+        const double mid = sqrt(a * b);
+        ladder_of(mid, lo);
+        if (ladder_mean(lo) < out->mean_degree) a = mid; else b = mid;
+    }
+    ladder_of(b, out->ladder);
+    return 0;
+}
+// host statements of two of the closed forms (a `synth:` server builds its seed lists and their labels on the host)
+int32_t legion_synth_label_host(int32_t v, int32_t classes) { return (int32_t)(sm64(S_LAB + (uint64_t)(uint32_t)v) % (uint64_t)classes); }
+int32_t legion_synth_seed_id_host(int64_t i, int32_t V, uint32_t M2, uint32_t C2) { return (int32_t)(((uint64_t)i * (uint64_t)M2 + (uint64_t)C2) % (uint64_t)(uint32_t)V); }
 void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, int32_t V, uint32_t M2, uint32_t C2,
                            int32_t stride, int32_t phase)
 {

@@ -86,7 +86,9 @@ std::vector<int32_t> get_steps()
 void Synchronize()
 {
     require_env();
-    legion_ipc_client_post(env); // env->Post(), ipc_service.cpp:83-85
+    // env->Post(), ipc_service.cpp:83-85.  legion_ipc_client_post waits for the device first: the reference trainers call this with
+    // their optimizer step still queued (legion_graphsage.py:93-116), and a posted pipe is overwritten by the server
+    legion_ipc_client_post(env);
 }
 
 int get_hops() { return g_hops; }

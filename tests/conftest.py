@@ -27,10 +27,17 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def assert_batch_equal(ref, got, keys=("nc", "ec", "ids", "labels", "src_off", "dst_off", "features")):
+BATCH_KEYS = ("nc", "ec", "ids", "labels", "src_off", "dst_off", "features")
+KEYS_NO_FEATURES = BATCH_KEYS[:-1]      # a run that gathers nothing (pre-sampling batches, gather=False oracle runs): say so explicitly
+
+
+def assert_batch_equal(ref, got, keys=BATCH_KEYS):
+    """Every buffer named in `keys` must be present on BOTH sides and equal word for word.  A key missing from either side is a
+    failure (round 4 skipped it silently: a renamed field of Engine.result() or of the oracle wrapper would have turned a parity
+    test into a no-op for that buffer) -- a caller that means to leave a buffer out passes `keys=` without it."""
     for k in keys:
-        if k not in ref or k not in got:
-            continue
+        assert k in ref, f"{k}: missing from the reference batch (has {sorted(ref)})"
+        assert k in got, f"{k}: missing from the batch under test (has {sorted(got)})"
         a, b = np.asarray(ref[k]), np.asarray(got[k])
         assert a.shape == b.shape, f"{k}: shape {a.shape} vs {b.shape}"
         if not np.array_equal(a, b):

@@ -26,7 +26,23 @@ def main():
     hops = ipc_service.get_hops()
     total = (train_steps + valid_steps) * epochs + test_steps
     recs = []
+    queued = os.environ.get("LEGION_CLIENT_QUEUED_WORK") == "1"
     for b in range(total):
+        if queued:
+            # A reference-style trainer (legion_graphsage.py:93-116): it posts the pipe with its device work still QUEUED and never
+            # synchronises on its own.  A long spin kernel sits in front of the copies that read the batch; the digests are taken from
+            # those copies after the post.  If synchronize() handed the pipe back before the queued copies ran, the server would
+            # overwrite it (depth 2: batch b + 2) and the digests would be another batch's.
+            tensors = ipc_service.get_next(feat_dim)
+            sizes = ipc_service.get_block_size()
+            torch.cuda._sleep(40_000_000)                      # ~ 20 ms on the device, queued asynchronously
+            snap = [t.clone() for t in tensors]                # queued behind the spin; still unexecuted when we post
+            ipc_service.synchronize()
+            ids, feats, labels = snap[:3]
+            blocks = snap[3:]
+            recs.append(dict(b=b, n=int(ids.shape[0]), sizes=list(sizes), ids=sha(ids), features=sha(feats), labels=sha(labels),
+                             edges=[int(blocks[2 * k].numel()) for k in range(hops)], src=sha(blocks[0]), dst=sha(blocks[1])))
+            continue
         tensors = ipc_service.get_next(feat_dim)
         sizes = ipc_service.get_block_size()
         ids, feats, labels = tensors[:3]

@@ -53,8 +53,8 @@ class FakeProc:
 def _launch(procs, **kw):
     started = []
 
-    def popen(cmd, env):
-        started.append((cmd, env))
+    def popen(cmd, env, stdout=None):
+        started.append((cmd, env, stdout))
         return procs[len(started) - 1]
     args = bench.parse(["--gpus", str(len(procs))])
     rc = bench.launch_children(args, ["--gpus", str(len(procs)), "--steps", "3"], popen=popen, poll_s=0.0, **kw)
@@ -65,10 +65,12 @@ def test_parent_starts_n_children_and_passes_the_flags_through():
     procs = [FakeProc([False, True], 0) for _ in range(4)]
     rc, started = _launch(procs)
     assert rc == 0 and len(started) == 4
-    for r, (cmd, env) in enumerate(started):
+    for r, (cmd, env, stdout) in enumerate(started):
         assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "3"]
         assert env["RANK"] == str(r) and env["WORLD_SIZE"] == "4"
-    assert len({env["MASTER_PORT"] for _, env in started}) == 1
+        assert (stdout is None) == (r == 0) and (r == 0 or stdout is sys.stderr)      # only rank 0 keeps the command's stdout
+        assert float(env["LEGION_BENCH_T0"]) > 0                                      # the time budget counts from the parent's start
+    assert len({env["MASTER_PORT"] for _, env, _ in started}) == 1
     assert not any(p.killed for p in procs)
 
 
@@ -128,9 +130,10 @@ def test_a_leg_that_hangs_prints_the_headline_names_the_leg_and_exits_3():
             "    time.sleep(60)\n"
             "g.run('unified_cache', 0.5, stuck)\n"
             "print('never')\n")
-    # N = 1 (the driver's BENCH run): nobody waits for this process and everything printed is valid -> the line, exit code 0
+    # N = 1 (the driver's BENCH run): the line is printed (headline and finished legs are valid), but a watchdog that fired on a
+    # process that has touched the GPU never exits 0: the same documented code as at N > 1
     r1 = subprocess.run([sys.executable, "-c", code % (ROOT, 1)], capture_output=True, text=True, timeout=60, cwd=ROOT)
-    assert r1.returncode == 0 and "never" not in r1.stdout and '"hung": true' in r1.stdout
+    assert r1.returncode == bench.LEG_HUNG_EXIT and "never" not in r1.stdout and '"hung": true' in r1.stdout
     r = subprocess.run([sys.executable, "-c", code % (ROOT, 2)], capture_output=True, text=True, timeout=60, cwd=ROOT)
     assert r.returncode == bench.LEG_HUNG_EXIT == 3 and "never" not in r.stdout
     import json
@@ -224,7 +227,7 @@ def test_extra_leg_plan():
         c = C()
         c.world, c.args = world, bench.parse(list(flags))
         return bench.extra_leg_names(c)
-    assert names(1) == ["lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]     # legs that re-use the headline graph first
+    assert names(1) == ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]     # legs that re-use the headline graph first
     assert names(8) == ["lp", "uk_union"] and names(2) == ["lp", "uk_union"]                              # the multi-GPU command is frozen (r03 keys)
     assert names(1, "--extra-legs", "none") == [] and names(8, "--extra-legs", "none") == []
     assert names(1, "--workload", "products") == [] and names(1, "--task", "lp") == [] and names(1, "--headline-only") == []   # auto: default workload only
@@ -233,3 +236,98 @@ def test_extra_leg_plan():
     import pytest
     with pytest.raises(SystemExit):
         names(1, "--extra-legs", "nonsense")
+
+
+# ---- the first multi-GPU run must not be lost to plumbing --------------------------------------------------------------
+_FAKE_WORKER = ("import os, sys, subprocess; sys.path.insert(0, %r)\n"
+                "import bench\n"
+                "bench.claim_stdout()                       # what worker() does first\n"
+                "rank = int(os.environ['RANK'])\n"
+                "print('python noise of rank %%d' %% rank, flush=True)\n"
+                "os.write(1, b'raw fd-1 noise (a C++ std::cout / printf of the library)\\n')\n"
+                "subprocess.run(['echo', 'noise of a child process of rank %%d' %% rank])\n"
+                "assert os.environ.get('LEGION_LOG') == 'stderr'\n"
+                "if rank == 0:\n"
+                "    bench.emit_line({'metric': 'm', 'value': 1.5, 'n_gpus': int(os.environ['WORLD_SIZE'])})\n"
+                "print('more noise after the line', flush=True)\n") % ROOT
+
+
+def test_stdout_of_a_4_rank_launch_is_one_json_line_whatever_the_ranks_print(tmp_path):
+    """Real processes: the self-launching parent starts 4 ranks that all print to stdout -- from Python, from file descriptor 1 directly
+    (the HIP library's std::cout chatter: "xGMI Clique ...", "Feature Cache Hit ...") and from their own children.  The command's stdout
+    must hold exactly the one JSON line of rank 0; everything else arrives on stderr."""
+    fake = tmp_path / "fake_worker.py"
+    fake.write_text(_FAKE_WORKER)
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "args = bench.parse(['--gpus', '4'])\n"
+            "sys.exit(bench.launch_children(args, ['--gpus', '4'], script=%r))\n") % (ROOT, str(fake))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LEGION_LOG")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0]) == {"metric": "m", "value": 1.5, "n_gpus": 4}
+    for rank in range(4):
+        assert "python noise of rank %d" % rank in r.stderr and "noise of a child process of rank %d" % rank in r.stderr
+    assert r.stderr.count("raw fd-1 noise") == 4 and r.stderr.count("more noise after the line") == 4
+
+
+def test_time_budget_arithmetic():
+    clock = [1000.0]
+    b = bench.Budget(480.0, t0=1000.0, now=lambda: clock[0])
+    assert b.left() == 480.0
+    assert b.grant(240.0, 60.0) == 240.0                      # plenty left: the leg's own timeout
+    clock[0] += 300.0                                         # 180 s left, 15 s reserve
+    assert b.grant(240.0, 60.0) == 165.0                      # clamped to what is left minus the reserve
+    assert b.grant(150.0, 30.0) == 150.0
+    clock[0] += 120.0                                         # 60 s left
+    assert b.grant(240.0, 60.0) == 0.0                        # 45 s < the 60 s the leg needs: skipped
+    assert b.grant(150.0, 30.0) == 45.0
+    clock[0] += 100.0                                         # over budget
+    assert b.grant(150.0, 30.0) == 0.0 and b.left() < 0
+    assert bench.Budget(0.0, t0=0.0, now=lambda: 1e9).grant(150.0, 30.0) == 150.0       # --time-budget 0: no budget
+    # the parent's start time reaches the ranks through LEGION_BENCH_T0
+    assert bench.Budget(480.0, "123.5").t0 == 123.5
+    # the worst case of the default command fits the driver's 600 s limit: every grant ends before budget - reserve
+    a = bench.parse([])
+    assert a.time_budget <= 480.0 and a.time_budget + 60.0 <= 600.0
+
+
+def test_a_hung_leg_and_the_budget_the_line_is_printed_in_time():
+    """Budget 6 s: leg A hangs -> it gets what the budget grants (not its own 240 s timeout), the watchdog prints the line with the headline,
+    names the leg and exits non-zero, all well inside the budget.  And a leg that the budget cannot admit any more is skipped, named in
+    legs_skipped, and the line is printed normally."""
+    code = ("import sys, json, time; sys.path.insert(0, %r)\n"
+            "import bench, legion1_amd.dist as D\n"
+            "bench.Budget.RESERVE_S = 1.0\n"
+            "bench.LEG_LEAST_S.update(unified_cache=2.0, lp=2.0, quick=1.0)\n"
+            "class _Ctx:\n"
+            "    rank, world, D, children = 0, 1, D, []\n"
+            "c = _Ctx(); c.budget = bench.Budget(%%s)\n"
+            "line = {'metric': 'm', 'value': 42.0, 'legs_failed': [], 'legs_skipped': [], 'extra_legs': {}}\n"
+            "g = bench.LegGuard(c, line)\n"
+            "t0 = time.time()\n"
+            "%%s\n"
+            "bench.emit_line(line)\n") % ROOT
+    hang = ("line['extra_legs']['quick'] = bench.run_budgeted(c, line, g, 'quick', 240.0, lambda: {'value': 1.0})\n"
+            "line['unified_cache'] = bench.run_budgeted(c, line, g, 'unified_cache', 240.0, lambda: time.sleep(600))\n")
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code % ("6.0", hang)], capture_output=True, text=True, timeout=60, cwd=ROOT)
+    took = time.time() - t0
+    import json
+    assert r.returncode == bench.LEG_HUNG_EXIT and took < 12.0, (r.returncode, took, r.stderr[-1500:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] == 42.0 and line["extra_legs"]["quick"] == {"value": 1.0}
+    assert line["legs_failed"][0]["leg"] == "unified_cache" and line["legs_failed"][0]["hung"] is True
+    assert "did not finish within 5 s" in line["legs_failed"][0]["error"]           # 6 s budget - 1 s reserve, not the leg's 240 s
+    skip = ("time.sleep(4.5)\n"
+            "line['extra_legs']['lp'] = bench.run_budgeted(c, line, g, 'lp', 150.0, lambda: {'value': 2.0})\n")
+    r = subprocess.run([sys.executable, "-c", code % ("6.0", skip)], capture_output=True, text=True, timeout=60, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads(r.stdout.splitlines()[-1])
+    assert line["extra_legs"]["lp"] == {"skipped": "time budget"} and line["legs_skipped"][0]["leg"] == "lp" and line["legs_failed"] == []

@@ -22,6 +22,8 @@ def _bench(extra_env, *flags, timeout=400, gpus=2):
                         "--min-time", "0.05", "--extra-min-time", "0.05", "--presc-steps", "2"] + list(flags),
                        env=env, capture_output=True, text=True, timeout=timeout)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # whatever the ranks, the HIP library and their children print, the command's stdout is the ONE JSON line
+    assert r.stdout.count("\n") <= 1 and len(lines) == len(r.stdout.splitlines()), r.stdout[:2000]
     return r, (json.loads(lines[-1]) if lines else None)
 
 
@@ -29,6 +31,11 @@ def test_two_rank_line_has_every_leg():
     r, line = _bench({})
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 2 and line["legs_failed"] == [] and line["value"] > 0 and line["value_overlap"] > 0
+    # next 2c: the CPU baseline (short, sampler only, rank 0) and the roofline are in the N > 1 line too; nothing was skipped
+    assert line["legs_skipped"] == [] and line["roofline"]["frac"] > 0 and line["time_budget"]["used_s"] < line["time_budget"]["budget_s"]
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and "no feature gather" in cb["sample"] and cb["seconds"] <= 5.0
+    assert "xGMI Clique" in r.stderr or "Feature Cache" in r.stderr or "Start solve cost model" in r.stderr      # the library's chatter: stderr
     u = line["unified_cache"]
     assert u["Kg"] == 2 and u["value"] > 0 and min(u["rows_last_batch"][k] for k in ("own_shard", "peer_shards", "backing_table")) > 0
     x = u["exchange_variant"]
@@ -79,7 +86,13 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 1 and line["legs_failed"] == [] and line["value"] > 0 and line["cpu_baseline"]["value"] > 0
     legs = line["extra_legs"]
-    assert list(legs) == ["lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]
+    assert list(legs) == ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]
+    sv = legs.pop("served")
+    # the server binary (dataset source synth:papers100M:0.02) + a consumer process, as fresh children of the bench
+    assert sv.get("error") is None and sv["value"] > 0 and sv["ms_per_step"] > 0 and sv["windows"] >= 1, sv
+    assert sv["schedule"]["train_steps"] == (int(11105995 * 0.02) - 1) // 8000 and sv["schedule"]["epochs"] >= 2
+    assert sv["served_batches_equal_the_timed_ones"] is True and sv["server_tables"] == "generated in HBM"
+    assert sv["ratio_to_alt_schedule_levels"] > 0 and sv["fanout"] == [25, 10, 5] and sv["F"] == 128
     for name, leg in legs.items():
         assert leg.get("error") is None and leg["value"] > 0 and leg["ms_per_step"] > 0, (name, leg)
         assert 0 < leg["gather_frac_of_hbm_peak"] < 1 and leg["sampler_us_per_batch"] > 0 and 0 < leg["pipeline_frac"] < 1, (name, leg)
@@ -91,6 +104,7 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     assert p2["fanout"] == [25, 10] and p3["fanout"] == [25, 10, 5] and p2["F"] == p3["F"] == 100
     assert p2["cpu_baseline"]["value"] > 0 and p2["cpu_baseline"]["dgl_semantics"]["value"] > 0 and "cpu_baseline" not in p3
     assert p3["value_overlap"] > 0 and p3["pipeline_frac_overlap"] > 0
+    assert "training batches per epoch" in p2["served"]["error"]          # 2 % of products has no full training batch: reported, not fatal
     pc = legs["partitioned_csr"]
     assert pc["F"] == 256 and pc["fanout"] == [25, 10] and pc["topo_rows_per_gpu"] > 0 and pc["Kg"] == 1
 

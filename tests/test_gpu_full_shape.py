@@ -324,3 +324,79 @@ def test_full_shape_matches_oracle(K, oracle, synth, workload):
         del orc
     del feats, indices, indptr
     torch.cuda.empty_cache()
+
+
+def test_synth_server_serves_the_headline_shape(K, oracle, synth, tmp_path):
+    """The `legion` server binary with the dataset source `synth:papers100M` (tables generated in HBM, no files), {25,10,5}, B = 8000 --
+    what bench.py's `served` leg times -- handing batches to a trainer-side process over shm + semaphores + IPC handles (Server.cu:301-328,
+    CUDA_IPC_Service.cu:289-297, ipc_cuda_kernel.cu:98-107,178-230).  The first, the middle and the last served training batch, the
+    validation and the test batch are compared word for word with the OpenMP oracle on a host copy of the same CSR; batches 0 and 694
+    also with the SERIAL oracle's digests from the build container (tests/golden/full_shape_digests.json); every served feature row of those
+    batches with the generator's closed form (SHA-256 over all rows)."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT, sha
+    server_bin = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
+    fields, cases = _full_shape_cases("papers100M")
+    case = cases["papers100M-25,10,5"]
+    B, fan, H = case["batch"], case["fanout"], 3
+    spec = synth.spec_for("papers100M")
+    n_eval = 512
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write("synth:papers100M %d %d %d %d %d %d %d 0 1 0" % (B, spec.V, case["E"], spec.F, spec.n_train, n_eval, n_eval))
+    env = dict(os.environ, LEGION_IPC_NAMESPACE="fs%d_" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_CLIENT_DUMP_IDS="1")
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([server_bin, "1", "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=str(tmp_path))
+    out = str(tmp_path / "client.json")
+    train_step = (spec.n_train - 1) // B
+    record = [0, train_step // 2, train_step - 1, train_step, train_step + 1]
+    assert record[1] == 694
+    try:
+        t0 = time.time()
+        while "System is ready for serving" not in open(log, errors="ignore").read():
+            assert server.poll() is None, open(log).read()[-3000:]
+            assert time.time() - t0 < 300, open(log).read()[-3000:]
+            time.sleep(0.2)
+        client = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ipc_client_plain.py"), str(spec.F), "1", out, ",".join(map(str, record))],
+                                env=env, capture_output=True, text=True, timeout=600)
+        assert client.returncode == 0, client.stdout[-2000:] + client.stderr[-3000:]
+        server.wait(timeout=120)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        if server.poll() is None:
+            server.kill()
+    text = open(log).read()
+    assert "Graph generated in HBM: %d edges" % case["E"] in text and "Train Steps: %d" % train_step in text
+    got = json.load(open(out))
+    assert got["steps"] == [train_step, 1, 1] and got["hops"] == H and [r["b"] for r in got["batches"]] == record
+    # the oracle side: the CSR from the independent C generator on the host (oracle/synth_gen.c, OpenMP)
+    h_indptr, h_indices = oracle.synth_csr(spec)
+    assert int(h_indptr[-1]) == case["E"] and sha(h_indptr) == case["indptr_sha256"]
+    orc = oracle.OracleRunner(h_indptr, h_indices, None, spec.V, spec.F, B, fan, with_features=False)
+    n1, n2 = spec.n_train, spec.n_train + spec.n_valid
+    sets = {0: synth.seed_ids(spec, 0, n1), 1: synth.seed_ids(spec, n1, n1 + n_eval), 2: synth.seed_ids(spec, n2, n2 + n_eval)}
+    assert sha(sets[0]) == case["seeds_sha256"]
+    golden = {w["counter"]: w for w in case["batches"]}
+    for rec in got["batches"]:
+        mode, local = (0, rec["b"]) if rec["b"] < train_step else ((1, 0) if rec["b"] == train_step else (2, 0))
+        ids = sets[mode]
+        ref = orc.run_batch(ids, synth.labels(spec, ids), local, mode=mode, batch_size=B if mode == 0 else n_eval, gather=False, omp=(mode == 0))
+        assert rec["nc"] == ref["nc"].tolist() and rec["ec"] == ref["ec"].tolist(), rec["b"]
+        assert rec["ids"] == sha(ref["ids"]) and rec["labels"] == sha(ref["labels"]), rec["b"]
+        assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"]), rec["b"]
+        if mode == 0 and local in golden:          # ... and the serial oracle's digests of the build container
+            w = golden[local]
+            assert (rec["n"], rec["e"]) == (w["n_nodes"], w["n_edges"])
+            assert rec["ids"] == w["ids_sha256"] and rec["src"] == w["src_off_sha256"] and rec["dst"] == w["dst_off_sha256"] and rec["labels"] == w["labels_sha256"]
+        served_ids = np.load(out + ".ids%d.npy" % rec["b"])
+        assert np.array_equal(served_ids, ref["ids"])
+        h = hashlib.sha256()
+        for r0 in range(0, len(served_ids), 1 << 16):
+            h.update(np.ascontiguousarray(synth.features(spec, served_ids[r0:r0 + (1 << 16)])).tobytes())
+        assert rec["features"] == h.hexdigest(), rec["b"]

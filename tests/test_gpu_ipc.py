@@ -89,6 +89,114 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
     assert ("Tables stay in pinned host memory" if tables == "host" else "Tables replicated into HBM") in text
 
 
+@pytest.mark.parametrize("workload,scale,fan,B,G", [("products", 0.004, [5, 4, 3], 512, 1), ("papers100M", 0.0008, [25, 10], 1000, 1),
+                                                   ("uk-union", 0.0005, [10, 5], 512, 2)])
+def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, fan, B, G):
+    """meta_config dataset path `synth:<workload>:<scale>`: the server generates CSR + features in HBM with the legion_synth_* calls
+    (no files) -- what bench.py's `served` leg starts at the papers100M shape.  Every served batch (train, valid, test) must equal the
+    oracle run on the numpy statement of the same generator; G = 2: two logical GPUs, one trainer each, tid % G seed split."""
+    spec = synth.spec_for(workload, scale=scale)
+    ds = synth.generate(spec)
+    epochs, n_valid, n_test = 2, min(700, spec.n_valid), min(300, spec.n_test)     # the meta line takes the first n ids of each range
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write("synth:%s:%r %d %d %d %d %d %d %d %d %d 0" % (workload, scale, B, spec.V, ds.E, spec.F, spec.n_train, n_valid, n_test, 1 << 40, epochs))
+    ns = "sy%d_%s_" % (os.getpid(), workload[:2])
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([SERVER, str(G), "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=str(tmp_path))
+    clients = []
+    try:
+        _wait_ready(server, log)
+        for g in range(G):
+            out = str(tmp_path / ("client%d.json" % g))
+            clients.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_client.py"), str(spec.F), str(epochs), out],
+                                                  env=dict(env, LEGION_IPC_DEVICE=str(g)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for out, c in clients:
+            stdout, _ = c.communicate(timeout=300)
+            assert c.returncode == 0, stdout[-3000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        for _, c in clients:
+            if c.poll() is None:
+                c.kill()
+        if server.poll() is None:
+            server.kill()
+    text = open(log).read()
+    assert "Graph generated in HBM: %d edges" % ds.E in text and "Tables generated in HBM" in text and "Server Stopped" in text
+    H = len(fan)
+    parts = {0: oracle.split_seeds(ds.train, G), 1: oracle.split_seeds(ds.valid[:n_valid], G), 2: oracle.split_seeds(ds.test[:n_test], G)}
+    steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+    for g in range(G):
+        got = json.load(open(clients[g][0]))
+        assert got["hops"] == H and got["steps"] == steps.tolist() and len(got["batches"]) == oracle.max_step(steps, epochs)
+        bs = {0: int(tb[g]), 1: int(vb[g]), 2: int(sb[g])}
+        for rec in got["batches"]:
+            mode, local = oracle.schedule(steps, epochs, rec["b"])
+            ids = parts[mode][g]
+            ref = orc.run_batch(ids, ds.labels[ids], local, mode=mode, batch_size=bs[mode])
+            assert rec["n"] == ref["nc"][5 + 2 * H] and rec["edges"] == [int(ref["ec"][2 + (H - k + 1)]) for k in range(1, H + 1)]
+            assert rec["ids"] == sha(ref["ids"]) and rec["features"] == sha(ref["features"]) and rec["labels"] == sha(ref["labels"])
+            assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
+
+
+def test_server_synth_dataset_source_refuses_a_wrong_meta_line(tmp_path, synth):
+    """V / F / E / seed-set sizes of the meta line that are not the generator's: the server stops with an error, no trainer is ever posted."""
+    spec = synth.spec_for("products", scale=0.004)
+    for bad in ("synth:products:0.004 512 %d 0 %d 10 10 10 0 1 0" % (spec.V + 1, spec.F),
+                "synth:products:0.004 512 %d 12345 %d 10 10 10 0 1 0" % (spec.V, spec.F),
+                "synth:products:0.004 512 %d 0 %d %d 10 10 0 1 0" % (spec.V, spec.F, spec.n_train + 1),
+                "synth:nothing 512 %d 0 %d 10 10 10 0 1 0" % (spec.V, spec.F)):
+        meta = str(tmp_path / "meta_config")
+        with open(meta, "w") as f:
+            f.write(bad)
+        env = dict(os.environ, LEGION_IPC_NAMESPACE="sybad%d_" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([SERVER, "1", "0", "5,4", meta], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1 and "Server_Initialize" in r.stderr and "ready for serving" not in r.stdout, (bad, r.stdout[-500:], r.stderr[-500:])
+
+
+def test_synchronize_with_queued_trainer_work(tmp_path, synth, oracle):
+    """get_next reads the host mirror of the counters and no longer synchronises the trainer's device (the
+    reference's blocking counter copy did, ipc_cuda_kernel.cu:195-196), and the reference trainers post with work still queued
+    (legion_graphsage.py:93-116).  ipc_service.synchronize() must therefore wait for the device BEFORE it posts: a trainer that queues a
+    long kernel in front of its reads of the batch and posts at once must still see every batch intact."""
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    B, epochs, fan = 512, 3, [10, 5]
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write("synth:products:0.004 %d %d %d %d %d %d %d 0 %d 0" % (B, spec.V, ds.E, spec.F, spec.n_train, spec.n_valid, 600, epochs))
+    env = dict(os.environ, LEGION_IPC_NAMESPACE="qw%d_" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_CLIENT_QUEUED_WORK="1")
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([SERVER, "1", "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=str(tmp_path))
+    try:
+        _wait_ready(server, log)
+        out = str(tmp_path / "client.json")
+        client = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ipc_client.py"), str(spec.F), str(epochs), out],
+                                env=env, capture_output=True, text=True, timeout=300)
+        assert client.returncode == 0, client.stdout[-2000:] + client.stderr[-3000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        if server.poll() is None:
+            server.kill()
+    got = json.load(open(out))
+    sets = {0: ds.train, 1: ds.valid, 2: ds.test[:600]}
+    steps, tb, vb, sb = oracle.coordinate([len(sets[0])], [len(sets[1])], [len(sets[2])], B)
+    bs = {0: int(tb[0]), 1: int(vb[0]), 2: int(sb[0])}
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+    assert len(got["batches"]) == oracle.max_step(steps, epochs) > 8
+    for rec in got["batches"]:
+        mode, local = oracle.schedule(steps, epochs, rec["b"])
+        ref = orc.run_batch(sets[mode], ds.labels[sets[mode]], local, mode=mode, batch_size=bs[mode])
+        assert rec["ids"] == sha(ref["ids"]) and rec["features"] == sha(ref["features"]) and rec["labels"] == sha(ref["labels"]), rec["b"]
+        assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"]), rec["b"]
+
+
 @pytest.mark.parametrize("peer_gather", ["in-kernel", "exchange", "graph3"])
 def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle, peer_gather):
     """`legion 2 1`: two logical GPUs in ONE server process (a thread per GPU, Server.cu:119-127), Kg = 2 unified

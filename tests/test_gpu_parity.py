@@ -9,7 +9,7 @@ import time
 import numpy as np
 import pytest
 
-from conftest import ROOT, assert_batch_equal, load_golden, sha
+from conftest import KEYS_NO_FEATURES, ROOT, assert_batch_equal, load_golden, sha
 
 pytestmark = pytest.mark.gpu
 
@@ -493,7 +493,7 @@ def test_presampling_cache_pipeline(K, oracle, small_ds, G, mode, chunk_bytes, p
         for it in range(steps):
             eng.run_batch(g, it, is_presc=True)
             ref = orcs[g].run_batch(parts[g], ds.labels[parts[g]], it, is_presc=True)
-            assert_batch_equal(ref, eng.result(g, with_features=False))
+            assert_batch_equal(ref, eng.result(g, with_features=False), keys=KEYS_NO_FEATURES)    # pre-sampling gathers nothing
             seen = max(seen, int(ref["nc"][5 + 2 * len(fan)]))
         L.SetGPUDevice(g)
         assert np.array_equal(K.read_dev(L.GPUCache_GetNodeAccessedMap(eng.cache, g), np.uint64, V), orcs[g].node_access_time)
@@ -937,7 +937,7 @@ def test_randomised_clique_cache_differential(K, oracle, seed, monkeypatch):
     for g in range(G):
         for it in range(steps):
             eng.run_batch(g, it, is_presc=True)
-            assert_batch_equal(orcs[g].run_batch(parts[g], labels[parts[g]], it, is_presc=True), eng.result(g, with_features=False))
+            assert_batch_equal(orcs[g].run_batch(parts[g], labels[parts[g]], it, is_presc=True), eng.result(g, with_features=False), keys=KEYS_NO_FEATURES)
     eng.build_cache(cache_agg_mode=mode, node_capacity=cap_n, edge_capacity=cap_e, train_step=steps)
     for Ki in range(G // Kg):
         members = list(range(Ki * Kg, (Ki + 1) * Kg))

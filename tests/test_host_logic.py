@@ -273,3 +273,33 @@ def test_cost_model_without_pcm_counters(oracle, synth):
         a = oracle.cost_model(AF, AT, QT, ds.indptr, V, spec.F, budget, 1, None, [5000], 24)
         b = oracle.cost_model(AF, AT, QT, ds.indptr, V, spec.F, budget, 1, [est, 0], [5000], 24)
         assert a == b
+
+
+def test_synth_spec_c_equals_python(synth):
+    """`legion_synth_spec` (csrc/synth.hip, host code) is what a `synth:` dataset source of the server generates from: every
+    field must equal synth.py's spec_for() for the three shapes at any scale -- ladder (80 bisection steps in IEEE doubles, Python's
+    round-half-even), the coprime multipliers, the shrunk seed sets."""
+    import ctypes as C
+    import legion1_amd.capi as K
+    L = K.lib()
+    for name in ("products", "papers100M", "uk-union"):
+        for scale in (1.0, 0.5, 0.3, 0.2, 0.1, 0.037, 0.01, 0.004, 0.002, 1e-5, 1e-7):
+            want = synth.spec_for(name, scale=scale)
+            got = K.LegionSynthSpec()
+            assert L.legion_synth_spec(name.encode(), scale, C.byref(got)) == 0
+            K.check()
+            assert (got.V, got.F, got.classes) == (want.V, want.F, want.classes), (name, scale)
+            assert (got.n_train, got.n_valid, got.n_test) == (want.n_train, want.n_valid, want.n_test), (name, scale)
+            assert (got.M, got.C, got.M2, got.C2) == (want.M, want.C, want.M2, want.C2), (name, scale)
+            assert list(got.ladder) == want.ladder.tolist(), (name, scale)
+            assert got.mean_degree == want.mean_degree
+            # the two host-side closed forms the server builds its seed lists from
+            ids = synth.seed_ids(want, 0, min(50, want.n_train))
+            assert [L.legion_synth_seed_id_host(i, want.V, want.M2, want.C2) for i in range(len(ids))] == ids.tolist()
+            lab = synth.labels(want, ids)
+            assert [L.legion_synth_label_host(int(v), want.classes) for v in ids] == lab.tolist()
+    bad = K.LegionSynthSpec()
+    for name, scale in ((b"nope", 1.0), (b"products", 0.0), (b"products", 1.5)):
+        assert L.legion_synth_spec(name, scale, C.byref(bad)) == -1
+        assert L.legion_last_error()
+        L.legion_clear_error()

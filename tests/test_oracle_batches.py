@@ -226,3 +226,29 @@ def test_full_shape_digests_products(oracle, synth):
             res = r.run_batch(seeds, lab, want["counter"], gather=False, omp=(i != 1))
             for f in gold["fields"]:
                 assert sha(res[f]) == want[f + "_sha256"], (name, want["counter"], f)
+
+
+def test_assert_batch_equal_is_strict_about_missing_buffers(oracle, small_ds):
+    """a buffer missing from either side fails the comparison (it used to be skipped silently); leaving a buffer
+    out is an explicit `keys=`."""
+    import pytest
+    from conftest import BATCH_KEYS, KEYS_NO_FEATURES
+    ds = small_ds
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, ds.spec.V, ds.spec.F, 64, [5, 3])
+    ref = orc.run_batch(ds.train, ds.labels[ds.train], 0)
+    assert set(BATCH_KEYS) <= set(ref)
+    assert_batch_equal(ref, dict(ref))
+    for k in BATCH_KEYS:
+        dropped = {x: v for x, v in ref.items() if x != k}
+        with pytest.raises(AssertionError, match=k + ": missing from the batch under test"):
+            assert_batch_equal(ref, dropped)
+        with pytest.raises(AssertionError, match=k + ": missing from the reference batch"):
+            assert_batch_equal(dropped, ref)
+    renamed = {("feats" if k == "features" else k): v for k, v in ref.items()}      # a renamed field is a missing field
+    with pytest.raises(AssertionError, match="features: missing"):
+        assert_batch_equal(ref, renamed)
+    assert_batch_equal(ref, renamed, keys=KEYS_NO_FEATURES)                         # ... unless the caller says it does not compare it
+    wrong = dict(ref, src_off=ref["src_off"].copy())
+    wrong["src_off"][3] ^= 1
+    with pytest.raises(AssertionError, match="src_off: 1 mismatches"):
+        assert_batch_equal(ref, wrong)

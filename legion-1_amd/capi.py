@@ -11,7 +11,22 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblegion_amd.so")
+DEFAULT_LIB_PATH = os.path.join(_HERE, "csrc", "liblegion_amd.so")
+
+
+def lib_path() -> str:
+    """The library this process loads: csrc/liblegion_amd.so, or the ABSOLUTE path in $LEGION_LIB -- a variant build of an experiment
+    (profiles/ab_kernels.sh) or the host-sanitizer build (make -C legion-1_amd/csrc asan-host).  Experiments point at their variant
+    through this and never overwrite the shipped library (round 4 swapped it in place: a killed run left an invalid library behind)."""
+    p = os.environ.get("LEGION_LIB")
+    if not p:
+        return DEFAULT_LIB_PATH
+    if not os.path.isabs(p):
+        raise RuntimeError(f"LEGION_LIB={p!r}: an absolute path is required (a relative one would depend on the working directory of every child process)")
+    return p
+
+
+LIB_PATH = DEFAULT_LIB_PATH      # kept for callers that print it; lib() resolves lib_path() when it loads
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "legion_amd.h")
 
 TRAINMODE, VALIDMODE, TESTMODE = 0, 1, 2
@@ -238,10 +253,11 @@ def lib():
     """The loaded HIP library.  Fails loudly when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C legion-1_amd/csrc` "
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C legion-1_amd/csrc` "
                                "(or __graft_entry__.build()); there is no CPU fallback")
-        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
         for name, (res, args) in _SIGS.items():
             fn = getattr(_lib, name)
             fn.restype = res

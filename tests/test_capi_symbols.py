@@ -65,9 +65,27 @@ def test_product_never_imports_the_oracle():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import legion1_amd.capi as K
     monkeypatch.setattr(K, "_lib", None)
-    monkeypatch.setattr(K, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(K, "DEFAULT_LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.delenv("LEGION_LIB", raising=False)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         K.lib()
+
+
+def test_legion_lib_selects_the_library_and_never_falls_back(monkeypatch, tmp_path):
+    """$LEGION_LIB: experiments and the sanitizer build point at THEIR library through it; a path that does not
+    exist or is relative is an error, never a silent load of the shipped library."""
+    import legion1_amd.capi as K
+    monkeypatch.setattr(K, "_lib", None)
+    monkeypatch.setenv("LEGION_LIB", str(tmp_path / "variant.so"))
+    assert K.lib_path() == str(tmp_path / "variant.so")
+    with pytest.raises(RuntimeError, match="variant.so is missing"):
+        K.lib()
+    monkeypatch.setenv("LEGION_LIB", "csrc/liblegion_amd.so")
+    with pytest.raises(RuntimeError, match="absolute path"):
+        K.lib()
+    monkeypatch.setenv("LEGION_LIB", K.DEFAULT_LIB_PATH)          # the shipped library named explicitly: loads, same symbols
+    assert K.lib().legion_version().startswith(b"legion-amd")
+    monkeypatch.setattr(K, "_lib", None)
 
 
 def test_c_abi_survives_null_arguments():

@@ -165,7 +165,7 @@ def test_synchronize_with_queued_trainer_work(tmp_path, synth, oracle):
     long kernel in front of its reads of the batch and posts at once must still see every batch intact."""
     spec = synth.spec_for("products", scale=0.004)
     ds = synth.generate(spec)
-    B, epochs, fan = 512, 3, [10, 5]
+    B, epochs, fan = 128, 3, [10, 5]
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
         f.write("synth:products:0.004 %d %d %d %d %d %d %d 0 %d 0" % (B, spec.V, ds.E, spec.F, spec.n_train, spec.n_valid, 600, epochs))

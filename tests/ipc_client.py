@@ -27,6 +27,7 @@ def main():
     total = (train_steps + valid_steps) * epochs + test_steps
     recs = []
     queued = os.environ.get("LEGION_CLIENT_QUEUED_WORK") == "1"
+    busy = torch.randn(4096, 4096, device="cuda") * 0.01 if queued else None
     for b in range(total):
         if queued:
             # A reference-style trainer (legion_graphsage.py:93-116): it posts the pipe with its device work still QUEUED and never
@@ -35,8 +36,11 @@ def main():
             # overwrite it (depth 2: batch b + 2) and the digests would be another batch's.
             tensors = ipc_service.get_next(feat_dim)
             sizes = ipc_service.get_block_size()
-            torch.cuda._sleep(40_000_000)                      # ~ 20 ms on the device, queued asynchronously
-            snap = [t.clone() for t in tensors]                # queued behind the spin; still unexecuted when we post
+            for _ in range(24):                                # tens of ms of queued device work (the "optimizer step")
+                busy = torch.tanh(busy @ busy)
+            # elementwise kernels reading the served buffers, queued behind that work and still unexecuted when we post
+            # (+ 0 on the integer view keeps every bit of the float rows)
+            snap = [(t.view(torch.int32) + 0).view(t.dtype) for t in tensors]
             ipc_service.synchronize()
             ids, feats, labels = snap[:3]
             blocks = snap[3:]

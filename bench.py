@@ -687,8 +687,11 @@ def served_leg(c, workload, fan, ref_leg):
     if not os.path.exists(server):
         raise RuntimeError("the server binary is missing: make -C legion-1_amd/csrc legion")
     train_step = (spec.n_train - 1) // B
-    if train_step < args.steps + args.warmup + 1:
-        raise RuntimeError("the shape has %d training batches per epoch; %d needed" % (train_step, args.steps + args.warmup + 1))
+    # windows of K consecutive training batches inside one epoch: a shape with few batches per epoch (products: 24) gets shorter windows
+    warm = min(args.warmup, train_step // 4)
+    K_win = min(args.steps, train_step - warm - 1)
+    if K_win < 4:
+        raise RuntimeError("the shape has %d training batches per epoch; at least %d needed" % (train_step, warm + 5))
     ref_ms = ref_leg["elapsed"] / args.steps * 1e3
     epochs = args.served_epochs or int(max(2, min(50, -(-2000.0 // (train_step * ref_ms)))))
     n_eval = min(512, spec.n_valid, spec.n_test)         # one validation / test batch per epoch: the schedule stays training batches
@@ -734,17 +737,17 @@ def served_leg(c, workload, fan, ref_leg):
     if ts != train_step or len(got["t"]) != (ts + vs) * epochs + es:
         raise RuntimeError("served schedule %s x %d epochs does not match the shape (train_step %d)" % (got["steps"], epochs, train_step))
     t, edges, nodes = got["t"], np.asarray(got["edges"], np.int64), np.asarray(got["nodes"], np.int64)
-    wins = served_schedule_windows(t, ts, vs, epochs, args.steps, args.warmup)
+    wins = served_schedule_windows(t, ts, vs, epochs, K_win, warm)
     secs = np.array([w[0] for w in wins])
     med = float(np.median(secs))
     is_train = np.array([(b % (ts + vs)) < ts for b in range((ts + vs) * epochs)] + [False] * es)
     e_mean, n_mean = float(edges[is_train].mean()), float(nodes[is_train].mean())
-    ms = med / args.steps * 1e3
-    # the batches this process timed (W .. W + K - 1 of the seed list) as the trainer received them: same edges, same rows
+    ms = med / K_win * 1e3
+    # the batches this process timed (W .. W + K - 1 of the seed list, modulo the epoch) as the trainer received them in epoch 0: same edges, same rows
     same = None
     if ref_leg.get("edges_per_step") is not None:
-        W = args.warmup
-        same = bool(np.array_equal(edges[W:W + args.steps], ref_leg["edges_per_step"]) and np.array_equal(nodes[W:W + args.steps], ref_leg["nodes_per_step"]))
+        idx = (args.warmup + np.arange(args.steps)) % ts
+        same = bool(np.array_equal(edges[idx], ref_leg["edges_per_step"]) and np.array_equal(nodes[idx], ref_leg["nodes_per_step"]))
     lv = (ref_leg.get("alt_levels") or {}).get("ms_per_step")
     ov = (ref_leg.get("alt") or {}).get("ms_per_step") if (ref_leg.get("alt") or {}).get("pipeline") == "overlap" else None
     train_t = float(sum(t[e * (ts + vs) + ts - 1] - t[max(e * (ts + vs) - 1, 0)] for e in range(epochs)))
@@ -755,7 +758,7 @@ def served_leg(c, workload, fan, ref_leg):
             "feature_GBps": round(n_mean * 4 * spec.F / (ms * 1e-3) / 1e9, 2), "batch": B, "fanout": list(fan), "V": spec.V, "F": spec.F,
             "schedule": {"train_steps": ts, "valid_steps": vs, "test_steps": es, "epochs": epochs, "batches_served": len(t),
                          "eval_batch_seeds": n_eval},
-            "windows": len(wins), "steps_per_window": args.steps,
+            "windows": len(wins), "steps_per_window": K_win,
             "window_ms_min_median_max": [round(float(secs.min()) * 1e3, 4), round(med * 1e3, 4), round(float(secs.max()) * 1e3, 4)],
             "all_training_batches_ms_per_step": round(train_t / (ts * epochs) * 1e3, 4),
             "edges_per_batch": round(e_mean, 1), "unique_nodes_per_batch": round(n_mean, 1),

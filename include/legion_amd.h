@@ -308,6 +308,11 @@ int32_t GPUCache_ShardPitch(const GPUCache* c);   /* floats between two rows of 
 float* GPUCache_GetShardChunk(const GPUCache* c, int32_t dev_id, int32_t chunk);
 int GPUCache_ExportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, void* handle64);
 int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk, const void* handle64);
+/* The geometry a shard was built with, to travel next to its exported handles: out4 = {pitch (floats), rows per chunk, chunks, rows}.
+ * An importer addresses the peer's rows with ITS OWN derived geometry, so CheckShardGeometry(owner, geom of the exporter) must return 0
+ * before the owner's chunks are imported; -1 (sticky error naming both) when they differ -- never a silent read at the wrong stride. */
+int GPUCache_ShardGeometry(const GPUCache* c, int32_t dev_id, int32_t out4[4]);
+int GPUCache_CheckShardGeometry(GPUCache* c, int32_t owner_dev, const int32_t geom4[4]);
 /* "Feature Cache Hit" metric (GPUCache.cu:130-147,414-425: feature_cache_hit every 500th batch, printed at the last level).
  * Every $LEGION_CACHE_HIT_PERIOD-th batch (default 500) the FindFeat pass of the cached gathers counts its hits into pinned,
  * device-mapped words; "<dev> Feature Cache Hit: <ratio>" is printed when the next sampling starts (no blocking copy).
@@ -443,6 +448,10 @@ void legion_ipc_client_post_nosync(LegionIPCClient* c);
 void* legion_ipc_client_buffer(LegionIPCClient* c, int32_t which);
 void legion_ipc_client_steps(LegionIPCClient* c, int32_t steps[3]);
 int32_t legion_ipc_client_hops(LegionIPCClient* c);
+/* rows the feature buffers of this client's device hold (0: the server did not say -- a reference server).  A batch whose node count
+ * exceeds it must not be viewed as [n, F]: the reference sizes the buffer from the pre-sampling epoch's training batches (Server.cu:275)
+ * and views it unchecked (ipc_cuda_kernel.cu:200). */
+int32_t legion_ipc_client_feature_rows(LegionIPCClient* c);
 /* both 16-int counters of the current pipe (ipc_cuda_kernel.cu:195-196): from the server's host mirror when it maintains one, else by
  * a blocking device copy like the reference */
 void legion_ipc_client_read_counters(LegionIPCClient* c, int32_t h_node_counter[16], int32_t h_edge_counter[16]);

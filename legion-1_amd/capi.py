@@ -171,6 +171,8 @@ _SIGS = {
     "GPUCache_ShardChunkRows": (i32, [vp, i32]),
     "GPUCache_ShardPitch": (i32, [vp]),
     "GPUCache_GetShardChunk": (vp, [vp, i32, i32]),
+    "GPUCache_ShardGeometry": (C.c_int, [vp, i32, vp]),
+    "GPUCache_CheckShardGeometry": (C.c_int, [vp, i32, vp]),
     "GPUCache_ExportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
     "GPUCache_ImportFeatureShardChunk": (C.c_int, [vp, i32, i32, vp]),
     "GPUCache_HitSampling": (vp, [vp, i32, C.c_int, C.c_int]),
@@ -222,7 +224,7 @@ _SIGS = {
     "legion_ipc_set_namespace": (None, [C.c_char_p]),
     "legion_ipc_client_open": (vp, [i32]), "legion_ipc_client_wait": (None, [vp]),
     "legion_ipc_client_post": (None, [vp]), "legion_ipc_client_post_nosync": (None, [vp]), "legion_ipc_client_buffer": (vp, [vp, i32]),
-    "legion_ipc_client_steps": (None, [vp, vp]), "legion_ipc_client_hops": (i32, [vp]),
+    "legion_ipc_client_steps": (None, [vp, vp]), "legion_ipc_client_hops": (i32, [vp]), "legion_ipc_client_feature_rows": (i32, [vp]),
     "legion_ipc_client_read_counters": (None, [vp, vp, vp]), "legion_ipc_client_close": (None, [vp]),
     "NewGPURunner": (vp, []), "Runner_Initialize": (None, [vp, vp]),
     "Runner_InitializeFeaturesBuffer": (None, [vp, vp]), "Runner_RunPreSc": (None, [vp, vp]),
@@ -531,11 +533,16 @@ class Engine:
 
     # ---- one process per GPU: exchange the clique's cache shards / CSR fragments over HIP IPC -----------------
     def export_shards(self, dev):
-        """(feature_chunk_handles, indptr_chunk_handles, indices_chunk_handles, (fragment_rows, fragment_edges)) of a
-        LOCAL clique member; every handle is a 64-byte HIP IPC handle of one chunk allocation."""
+        """(feature_chunk_handles, indptr_chunk_handles, indices_chunk_handles, (fragment_rows, fragment_edges), shard geometry) of a
+        LOCAL clique member; every handle is a 64-byte HIP IPC handle of one chunk allocation; the geometry -- (pitch, rows per
+        chunk, chunks, rows) the shard was built with -- travels with the handles and is checked by the importer."""
         L = self.L
         fh = []
+        geom = None
         if L.GPUCache_Float_Feature_Cache(self.cache, dev):
+            g4 = (i32 * 4)()
+            if L.GPUCache_ShardGeometry(self.cache, dev, g4) == 0:
+                geom = tuple(g4)
             for q in range(L.GPUCache_ShardChunkCount(self.cache, dev)):
                 b = C.create_string_buffer(64)
                 if L.GPUCache_ExportFeatureShardChunk(self.cache, dev, q, b) != 0:
@@ -552,13 +559,16 @@ class Engine:
                     th[which].append(b.raw)
         check()
         have_t = rows > 0 and th[0] and th[1]
-        return (fh if fh else None, th[0] if have_t else None, th[1] if have_t else None, (rows, edges))
+        return (fh if fh else None, th[0] if have_t else None, th[1] if have_t else None, (rows, edges), geom)
 
     def import_shards(self, owner_dev, handles, viewer_devs=None):
         """Open a REMOTE member's shards so that the local members read them in-kernel (xGMI peer loads)."""
         L = self.L
-        fh, ih, xh, (rows, edges) = handles
+        fh, ih, xh, (rows, edges) = handles[:4]
+        geom = handles[4] if len(handles) > 4 else None
         if fh is not None:
+            if geom is not None and L.GPUCache_CheckShardGeometry(self.cache, owner_dev, (i32 * 4)(*geom)) != 0:
+                check()      # raises: the exporter's pitch / chunk geometry is not what this process derived
             for q, h in enumerate(fh):
                 L.GPUCache_ImportFeatureShardChunk(self.cache, owner_dev, q, h)
         if ih is not None:

@@ -583,6 +583,32 @@ int GPUCache_ImportFeatureShardChunk(GPUCache* c, int32_t dev_id, int32_t chunk,
     publish_shard_tables(c, dev_id / c->Kg);
     return 0;
 }
+// What an importer has to agree with before it opens a peer's shard: it addresses the peer's rows as
+// chunk[r >> shift] + (r & mask) * pitch with ITS OWN pitch / chunk geometry (c->shard_pitch, chunk_shift, nchunks), each process having
+// derived them from its own alpha and capacity.  They travel next to the exported handles; a disagreement would read the peer's rows at the
+// wrong stride -- silently -- so it is refused.
+int GPUCache_ShardGeometry(const GPUCache* c, int32_t dev_id, int32_t out4[4])
+{
+    if (!c || !out4 || dev_id < 0 || dev_id >= c->device_count || c->nchunks.empty()) { LEGION_ARG_ERROR("ShardGeometry: no shard geometry yet (run FillUp)"); return -1; }
+    const int Ki = dev_id / c->Kg;
+    out4[0] = GPUCache_ShardPitch(c);
+    out4[1] = 1 << c->chunk_shift[Ki];
+    out4[2] = c->nchunks[Ki];
+    out4[3] = c->node_capacity[Ki];
+    return 0;
+}
+int GPUCache_CheckShardGeometry(GPUCache* c, int32_t owner_dev, const int32_t geom4[4])
+{
+    int32_t mine[4];
+    if (!geom4 || GPUCache_ShardGeometry(c, owner_dev, mine) != 0) { LEGION_ARG_ERROR("CheckShardGeometry: bad arguments"); return -1; }
+    if (mine[0] == geom4[0] && mine[1] == geom4[1] && mine[2] == geom4[2] && mine[3] == geom4[3]) return 0;
+    char msg[320];
+    snprintf(msg, sizeof(msg), "CheckShardGeometry: the shard of clique member %d was built with (pitch %d floats, %d rows per chunk, %d chunks, %d rows), "
+             "this process derived (%d, %d, %d, %d): refusing to import it (its rows would be read at the wrong stride)",
+             owner_dev, geom4[0], geom4[1], geom4[2], geom4[3], mine[0], mine[1], mine[2], mine[3]);
+    LEGION_ARG_ERROR(msg);
+    return -1;
+}
 int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64)
 {   // single-chunk shards only; chunked shards use the *Chunk calls
     if (GPUCache_ShardChunkCount(c, dev_id) != 1) { LEGION_ARG_ERROR("ExportFeatureShard: shard has several chunks, use ExportFeatureShardChunk"); return -1; }

@@ -130,6 +130,8 @@ struct SamplerBuffers {
     int32_t* aux_next;      // the other buffer: k_write prepares it (-1) for the next hop
     int32_t next_count;     // fan-out of the next hop (0: none)
     int32_t aux_cap;        // elements per aux buffer
+    int32_t ids_cap;        // elements of sampled_ids / agg_src_ids / agg_src_off / agg_dst_off (num_ids)
+    int32_t V;              // entries of pos_map
     bool aux_prepared;      // aux already holds -1 for nc[2] * count slots
     int32_t* tile_edge;     // i32[max tiles]
     int32_t* tile_node;     // i32[max tiles]

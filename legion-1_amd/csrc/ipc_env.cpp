@@ -15,6 +15,7 @@
 #include <fcntl.h>
 #include <iostream>
 #include <algorithm>
+#include <optional>
 #include <atomic>
 #include <vector>
 #include <poll.h>
@@ -40,9 +41,23 @@ struct shmStruct {
     // batch.  A client that finds the magic set reads the mirror instead; the device buffers 5 / 6 stay valid for everybody else.
     uint32_t ext_mirror_magic;
     int32_t ext_counters[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH][32];   // nc[16] | ec[16]
+    // extension: rows the feature buffers of a device hold (InitializeFeaturesBuffer; 0 = not told).  The reference sizes them at 1.2 x the
+    // largest batch of the pre-sampling epoch (Server.cu:275) and its trainer views [nc9, F] of them unchecked (ipc_cuda_kernel.cu:200): a
+    // batch with more nodes reads past the allocation.  A client that knows the capacity refuses such a batch instead.
+    int32_t ext_feature_rows[LEGION_MAX_DEVICE];
 };
 static_assert(offsetof(shmStruct, ext_hops) == 12 + 8 * 2 * 7 * 64, "reference shm layout changed");
 static const uint32_t kMirrorMagic = 0x4C474E43u;   // "LGNC"
+
+// $LEGION_IPC_NO_DEVICE=1 (test hook: build containers without a GPU, the host-sanitizer run of tests/test_ipc_env_cpu.py): the slab,
+// the named semaphores, the counter mirror and the poisoned-pipe protocol with no device call at all -- no hand-off buffer is
+// allocated, the handle slots stay zero (a client takes an all-zero handle as "no buffer"), nothing is page-locked.
+static bool no_device()
+{
+    static const bool v = [] { const char* e = getenv("LEGION_IPC_NO_DEVICE"); return e && e[0] == '1'; }();
+    return v;
+}
+#define LEGION_DEVICE_GUARD(dev) std::optional<DeviceGuard> guard_; if (!no_device()) guard_.emplace(dev)
 
 static std::string g_namespace;
 static bool g_ns_init = false;
@@ -302,6 +317,7 @@ static void pin_slab(IPCEnv* e)
     if (e->shm_pinned || !e->shm) return;
     const size_t page = (size_t)sysconf(_SC_PAGESIZE), bytes = (sizeof(shmStruct) + page - 1) / page * page;
     const char* no_pin = getenv("LEGION_IPC_NO_PIN");      // test hook: behave as if the runtime refused (the staging path below)
+    if (no_device()) { e->shm->ext_mirror_magic = kMirrorMagic; return; }
     if (!(no_pin && no_pin[0] == '1') && hipHostRegister((void*)e->shm, bytes, hipHostRegisterPortable) == hipSuccess) e->shm_pinned = true;
     else (void)hipGetLastError();
     e->shm->ext_mirror_magic = kMirrorMagic;    // the mirror is maintained either way (synchronously in IPCPost if need be)
@@ -341,6 +357,7 @@ int32_t IPCEnv_GetMaxStep(IPCEnv* e) { return ((e->train_step + e->valid_step) *
 static void* ipc_alloc(volatile shmStruct* shm, int dev, int pipe, int which, size_t bytes)
 {
     void* p = nullptr;
+    if (no_device()) return nullptr;      // handle slot stays zero
     // a trainer would stall forever inside ipc_service.initialize() on a buffer it cannot import
     if (!ipc_size_ok((int64_t)bytes, which == 1 ? "InitializeFeaturesBuffer (rows x F x 4 bytes of one pipe)" : "InitializeSamplesBuffer")) {
         if (!error_is_fatal()) return nullptr;
@@ -358,7 +375,7 @@ void IPCEnv_InitializeSamplesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_i
 {
     (void)feature_dim;
     if (!e || device_id < 0 || device_id >= e->device_count || pipeline_depth < 1 || pipeline_depth > LEGION_PIPELINE_DEPTH) { LEGION_ARG_ERROR("InitializeSamplesBuffer: bad arguments"); return; }
-    DeviceGuard guard(device_id);
+    LEGION_DEVICE_GUARD(device_id);
     e->semr[device_id].assign(pipeline_depth, nullptr);
     e->semw[device_id].assign(pipeline_depth, nullptr);
     for (int32_t i = 0; i < pipeline_depth; i++) {
@@ -368,17 +385,17 @@ void IPCEnv_InitializeSamplesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_i
         e->agg_dst[device_id].push_back(ipc_alloc(e->shm, device_id, i, 4, (size_t)num_ids * sizeof(int32_t)));
         e->node_counter[device_id].push_back(ipc_alloc(e->shm, device_id, i, 5, 16 * sizeof(int32_t)));
         e->edge_counter[device_id].push_back(ipc_alloc(e->shm, device_id, i, 6, 16 * sizeof(int32_t)));
-        HIP_CHECK(hipMemset(e->node_counter[device_id][i], 0, 16 * sizeof(int32_t)));
-        HIP_CHECK(hipMemset(e->edge_counter[device_id][i], 0, 16 * sizeof(int32_t)));
+        if (e->node_counter[device_id][i]) HIP_CHECK(hipMemset(e->node_counter[device_id][i], 0, 16 * sizeof(int32_t)));
+        if (e->edge_counter[device_id][i]) HIP_CHECK(hipMemset(e->edge_counter[device_id][i], 0, 16 * sizeof(int32_t)));
         // memory lock.  Stale semaphores of a crashed run are removed first (the reference only
         // unlinks in Finalize, CUDA_IPC_Service.cu:319-320, so a crash poisons the next start).
         const std::string ssri = sem_name("r", device_id, i), sswi = sem_name("w", device_id, i);
         sem_unlink(ssri.c_str());
         sem_unlink(sswi.c_str());
         e->semr[device_id][i] = sem_open(ssri.c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (e->semr[device_id][i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); return; }
+        if (e->semr[device_id][i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); e->semr[device_id][i] = nullptr; LEGION_ARG_ERROR("InitializeSamplesBuffer: sem_open(sem_r) failed"); return; }
         e->semw[device_id][i] = sem_open(sswi.c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (e->semw[device_id][i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); return; }
+        if (e->semw[device_id][i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); e->semw[device_id][i] = nullptr; LEGION_ARG_ERROR("InitializeSamplesBuffer: sem_open(sem_w) failed"); return; }
     }
     e->pipeline_depth = pipeline_depth;
 }
@@ -389,6 +406,7 @@ void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_
 {
     (void)batch_size;
     if (!e || device_id < 0 || device_id >= e->device_count) { LEGION_ARG_ERROR("InitializeFeaturesBuffer: bad arguments"); return; }
+    if (no_device()) return;
     DeviceGuard guard(device_id);
     const size_t bytes = (size_t)num_ids * feature_dim * sizeof(float);
     const char* force = getenv("LEGION_HANDOFF_VMM");
@@ -411,6 +429,7 @@ void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_
         if (!p) return;   // refused or out of memory: the error is sticky, nothing is registered
         e->float_features[device_id].push_back(p);
     }
+    e->shm->ext_feature_rows[device_id] = num_ids;
 }
 
 int32_t IPCEnv_GetRawBatchsize(IPCEnv* e) { return e->raw_batch_size; }
@@ -463,7 +482,7 @@ ENV_GETTER(EdgeCounter, edge_counter, int32_t)
 // pipe only after it has waited for that stream's work (the runner waits for an event recorded behind this call).
 void IPCEnv_MirrorCounters(IPCEnv* e, int32_t dev_id, int32_t current_pipe, void* stream)
 {
-    if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count || e->node_counter[dev_id].empty()) return;
+    if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count || e->node_counter[dev_id].empty() || no_device()) return;
     const int q = current_pipe % e->pipeline_depth;
     int32_t* m = (int32_t*)&e->shm->ext_counters[dev_id][q][0];
     if (!e->shm_pinned) {           // the runtime refused to page-lock the slab: queue the copies into pinned staging words, IPCPost moves them
@@ -493,7 +512,7 @@ void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
     const int q = current_pipe % e->pipeline_depth;
     if (e->shm && e->mirror_fresh[dev_id][q] && !e->shm_pinned && e->mirror_stage[dev_id][q])     // staged by a queued copy the caller has waited for
         for (int i = 0; i < 32; i++) e->shm->ext_counters[dev_id][q][i] = e->mirror_stage[dev_id][q][i];
-    if (e->shm && e->shm->ext_mirror_magic == kMirrorMagic && !e->mirror_fresh[dev_id][q] && !e->node_counter[dev_id].empty()) {
+    if (e->shm && e->shm->ext_mirror_magic == kMirrorMagic && !e->mirror_fresh[dev_id][q] && !e->node_counter[dev_id].empty() && !no_device()) {
         // a producer that did not queue the mirror copy (a reference-style RunOnce on this library): copy now -- the batch is
         // complete when a pipe is posted, so a blocking copy is correct, merely slower than the queued one
         DeviceGuard guard(dev_id);
@@ -504,11 +523,13 @@ void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
         else { (void)hipGetLastError(); e->shm->ext_mirror_magic = 0; }   // clients fall back to the device buffers
     }
     e->mirror_fresh[dev_id][q] = false;
-    sem_post(e->semw[dev_id][current_pipe]);
+    if (e->semw[dev_id][q]) sem_post(e->semw[dev_id][q]);
 }
 void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
 {
-    while (sem_wait(e->semr[dev_id][current_pipe]) != 0 && errno == EINTR) {}
+    sem_t* sem = e->semr[dev_id][current_pipe % e->pipeline_depth];
+    if (!sem) return;      // sem_open failed (sticky error): never block on a semaphore that does not exist
+    while (sem_wait(sem) != 0 && errno == EINTR) {}
 }
 int IPCEnv_IPCTryWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t timeout_ms)
 {
@@ -518,7 +539,9 @@ int IPCEnv_IPCTryWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t t
     ts.tv_nsec += (long)(timeout_ms % 1000) * 1000000L;
     if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
     int r;
-    while ((r = sem_timedwait(e->semr[dev_id][current_pipe], &ts)) != 0 && errno == EINTR) {}
+    sem_t* sem = e->semr[dev_id][current_pipe % e->pipeline_depth];
+    if (!sem) return -1;
+    while ((r = sem_timedwait(sem, &ts)) != 0 && errno == EINTR) {}
     return r == 0 ? 0 : -1;
 }
 
@@ -528,8 +551,15 @@ void IPCEnv_Finalize(IPCEnv* e)
     if (!e) return;
     for (int32_t i = 0; i < e->device_count; i++) {
         if (e->ids[i].empty()) continue;
-        DeviceGuard guard(i);
+        LEGION_DEVICE_GUARD(i);
         for (size_t j = 0; j < e->ids[i].size(); j++) {
+            if (no_device()) {       // nothing was allocated: only the semaphores exist
+                if (e->semw[i][j] && e->semw[i][j] != SEM_FAILED) sem_close(e->semw[i][j]);
+                if (e->semr[i][j] && e->semr[i][j] != SEM_FAILED) sem_close(e->semr[i][j]);
+                sem_unlink(sem_name("r", i, (int)j).c_str());
+                sem_unlink(sem_name("w", i, (int)j).c_str());
+                continue;
+            }
             (void)hipFree(e->ids[i][j]);
             if (j < e->float_features[i].size()) {
                 bool mapped = false;
@@ -646,7 +676,7 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
 {
     LegionIPCClient* c = new LegionIPCClient();
     int cur = 0;
-    HIP_CHECK(hipGetDevice(&cur));
+    if (!no_device()) HIP_CHECK(hipGetDevice(&cur));
     c->device = device_id >= 0 ? device_id : cur;
     // $LEGION_IPC_DEVICE: logical GPU (row of the shm handle table) when it differs from the physical device,
     // e.g. several logical GPUs of a clique exercised on one physical device
@@ -670,15 +700,18 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
                 }
                 continue;
             }
+            static const hipIpcMemHandle_t zero{};
+            if (memcmp(&h, &zero, sizeof(h)) == 0) continue;     // the server registered no buffer in this slot (a features buffer before
+                                                                 // PreSc, Server.cu:33,273-282; $LEGION_IPC_NO_DEVICE): nothing to open
             HIP_CHECK(hipIpcOpenMemHandle(&c->buf[i][w], h, hipIpcMemLazyEnablePeerAccess));
         }
     }
     log_out() << "HIP: " << c->device << " IPC shared memory opened\n";
     for (int i = 0; i < LEGION_PIPELINE_DEPTH; i++) {
         c->semr[i] = sem_open(sem_name("r", c->device, i).c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (c->semr[i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); return c; }
+        if (c->semr[i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); legion_ipc_client_close(c); return nullptr; }
         c->semw[i] = sem_open(sem_name("w", c->device, i).c_str(), O_CREAT | O_RDWR, 0666, 0);
-        if (c->semw[i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); return c; }
+        if (c->semw[i] == SEM_FAILED) { fprintf(log_file(), "errno = %d\n", errno); LEGION_ARG_ERROR("legion_ipc_client_open: sem_open"); legion_ipc_client_close(c); return nullptr; }
         sem_post(c->semr[i]); // both pipes start free (ipc_cuda_kernel.cu:91)
     }
     c->current_pipe = 0;
@@ -697,7 +730,7 @@ void legion_ipc_client_wait(LegionIPCClient* c)
 // as in the reference, and the pipe is really free when the server sees it.
 void legion_ipc_client_post(LegionIPCClient* c)
 {
-    HIP_CHECK(hipDeviceSynchronize());
+    if (!no_device()) HIP_CHECK(hipDeviceSynchronize());
     legion_ipc_client_post_nosync(c);
 }
 // ... for a consumer that has already waited for its own work (an event / stream synchronisation of its own, or no device work at all)
@@ -716,6 +749,7 @@ void legion_ipc_client_steps(LegionIPCClient* c, int32_t steps[3])
     for (int i = 0; i < 3; i++) steps[i] = c->steps[i];
 }
 int32_t legion_ipc_client_hops(LegionIPCClient* c) { return c->hops; }
+int32_t legion_ipc_client_feature_rows(LegionIPCClient* c) { return (c && c->shm) ? c->shm->ext_feature_rows[c->device] : 0; }
 void legion_ipc_client_read_counters(LegionIPCClient* c, int32_t h_node_counter[16], int32_t h_edge_counter[16])
 {
     if (c->shm->ext_mirror_magic == kMirrorMagic) {

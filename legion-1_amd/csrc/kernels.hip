@@ -478,7 +478,21 @@ struct WriteArgs {
     int32_t* aux_next;      // slot states of the next hop (the other buffer), set to "claim pending" here
     int32_t next_count;     // fan-out of the next hop (0: none)
     int32_t aux_cap;
+    int32_t ids_cap;        // elements of sampled_ids / agg_src_ids / agg_*_off (GPUMemoryPool::num_ids): bound of every store below
+    int32_t V;              // entries of pos_map
 };
+
+// Every store of k_write is addressed through the tile prefix (s_chunk[] + tile_pre[]) that k_mark left behind.  With a correct
+// k_mark the offsets are below the buffers' capacity by construction (num_ids = the sum of the static per-hop bounds); an experiment
+// that skips or breaks the prefix build writes through uninitialised offsets -- round 4's timing-only variant did, and hung its run
+// (profiles/r04_sampler.md).  The bound check makes such a variant drop the store instead of running away; it is one unsigned compare
+// per store in a kernel that waits for memory (measured: profiles/r05_sampler.md), so it stays on in the shipped build.
+// -DLEGION_UNBOUNDED_STORES removes it (the A/B that measured it).
+#ifdef LEGION_UNBOUNDED_STORES
+#define LEGION_STORE_OK(i, cap) true
+#else
+#define LEGION_STORE_OK(i, cap) ((uint32_t)(i) < (uint32_t)(cap))
+#endif
 
 __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
 {
@@ -599,6 +613,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             for (int q = 0; q < s * W + wave; q++) pe += s_e[q];
             const int32_t dst = c[s];
             const int32_t e = ebase + pe + re[s];
+            if (!LEGION_STORE_OK(e, a.ids_cap)) continue;
             if (!a.last_hop) a.agg_src_ids[e] = dst;   // the next hop's input list; nothing reads it after the last hop
             a.agg_dst_off[e] = dpos[s];
             // src-side offset (construct_graph, Kernels.cu:456-460) = position of the sampled neighbour
@@ -608,9 +623,9 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
                     p = h.node_base + nodes_before(w[s] / kTile, wpre[s]) + win_rank(p);
             } else if (is_win(p)) {  // this slot discovered the node: k_mark ranked it inside the tile
                 p = nbase + win_rank(p);
-                a.sampled_ids[p] = dst;
+                if (LEGION_STORE_OK(p, a.ids_cap)) a.sampled_ids[p] = dst;
                 // the scattered table store is only needed when a later hop may look the node up by id
-                if (!a.last_hop) a.pos_map[dst] = ((unsigned long long)epoch << 32) | (uint32_t)p;
+                if (!a.last_hop && LEGION_STORE_OK(dst, a.V)) a.pos_map[dst] = ((unsigned long long)epoch << 32) | (uint32_t)p;
             }
             a.agg_src_off[e] = p;
         }
@@ -1220,7 +1235,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     w.hs = b.hop_state; w.nc = b.nc; w.ec = b.ec; w.hops = hops; w.cand = b.cand; w.aux = b.aux; w.ctl = b.ctl; w.tile_edge = b.tile_edge; w.tile_node = b.tile_node;
     w.sampled_ids = b.sampled_ids; w.agg_src_ids = b.agg_src_ids; w.agg_src_off = b.agg_src_off;
     w.agg_dst_off = b.agg_dst_off; w.pos_map = b.pos_map; w.fdiv = a.fdiv; w.op_id = op_id; w.last_hop = (op_id / 2 == hops) ? 1 : 0;
-    w.aux_next = b.aux_next; w.next_count = b.next_count; w.aux_cap = b.aux_cap;
+    w.aux_next = b.aux_next; w.next_count = b.next_count; w.aux_cap = b.aux_cap; w.ids_cap = b.ids_cap; w.V = b.V;
     w.tile_pre = b.tile_pre; w.chunk_tot = b.chunk_tot; w.mark_grid = grid;
     // 17 KB of static LDS (the chunk prefix): 8 workgroups per CU
     const int wgrid = grid_for(max_tiles, 1, 8);

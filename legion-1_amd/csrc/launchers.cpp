@@ -139,6 +139,8 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
         }
     }
     b.aux_cap = p->max_slots;
+    b.ids_cap = p->num_ids;
+    b.V = p->V;
     b.aux_prepared = p->aux_ready_hop == hop && p->aux_ready_count == count;
     b.next_count = hop < p->hops ? p->fanout[hop] : 0;
     launch_sample_hop((hipStream_t)strm_hdl, csr, b, count, op_id, p->hops, (int32_t)slots, is_presc != 0);

@@ -129,6 +129,15 @@ void Runner_InitializeFeaturesBuffer(Runner* r, RunnerParams* params)
     DeviceGuard guard(r->local_dev_id);
     HIP_CHECK(hipStreamSynchronize(r->streams[0]));
     int64_t num_ids = (int64_t)(GPUCache_MaxIdNum(cache, r->local_dev_id) * 1.2);
+    // The pre-sampling epoch only sees TRAINING batches.  A validation / test batch (up to 512 seeds per GPU, CUDA_IPC_Service.cu:101-118)
+    // that is larger than the training batch reaches more nodes: scale the estimate by the seed ratio (unique nodes grow at most linearly
+    // with the seeds).  The reference sizes by the training batches alone (Server.cu:275) -- with its 8000-seed training batches the case
+    // does not arise; with a small --train_batch_size its trainer would read past the buffer.
+    {
+        const int raw = std::max(1, IPCEnv_GetRawBatchsize(env));
+        const int eval = std::max(IPCEnv_GetCurrentBatchsize(env, r->local_dev_id, LEGION_VALIDMODE), IPCEnv_GetCurrentBatchsize(env, r->local_dev_id, LEGION_TESTMODE));
+        if (eval > raw) num_ids = (int64_t)((double)num_ids * (double)eval / (double)raw);
+    }
     if (num_ids > r->num_ids) num_ids = r->num_ids;
     if (num_ids < 1) num_ids = r->num_ids;
     r->feature_rows = (int32_t)num_ids;

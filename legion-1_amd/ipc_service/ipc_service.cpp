@@ -50,6 +50,11 @@ std::vector<torch::Tensor> get_next(int feature_dim)
     const auto f32 = torch::TensorOptions().dtype(torch::kF32).device(device);
     const int H = g_hops;
     const int64_t n_nodes = h_node_counter[5 + 2 * H];
+    // the feature buffer holds a bounded number of rows (1.2 x the largest pre-sampled batch, Server.cu:275): a batch that reaches more
+    // nodes must not be viewed as [n, F] (the reference does, unchecked: ipc_cuda_kernel.cu:200 -- a read past the allocation)
+    const int64_t rows = legion_ipc_client_feature_rows(env);
+    TORCH_CHECK(rows <= 0 || n_nodes <= rows, "ipc_service: the batch has ", n_nodes, " nodes but the server's feature buffer holds ", rows,
+                " rows (sized from the pre-sampling epoch; use a training batch size >= the validation / test batch size)");
     std::vector<torch::Tensor> out;
     out.push_back(torch::from_blob(legion_ipc_client_buffer(env, 0), {n_nodes}, i32));
     out.push_back(torch::from_blob(legion_ipc_client_buffer(env, 1), {n_nodes, (int64_t)feature_dim}, f32));

@@ -1,16 +1,19 @@
-# Same-box A/B of two builds of liblegion_amd.so (the shipped one vs profiles/ab/liblegion_amd_old.so, built from an older
-# kernels.hip): per-hop kernel medians from rocprofv3 --kernel-trace, alternating new / old / new / old.
-#   bash profiles/ab_kernels.sh <outdir-under-gpurun_out> ["papers100M 25,10,5" "products 25,10,5" ...]
+# Same-box A/B of two builds of liblegion_amd.so: the shipped one ("new") against a VARIANT library ("old" / "var"), alternating
+# new / var / new / var, per-hop kernel medians from rocprofv3 --kernel-trace.  The variant is selected through $LEGION_LIB
+# (legion-1_amd/capi.py lib_path): the shipped library is never copied over or replaced (round 4 swapped it in place; a killed
+# run left an invalid library behind on that lease).
+#   make -C legion-1_amd/csrc variant VARIANT=unbounded VARIANT_FLAGS=-DLEGION_UNBOUNDED_STORES     # -> csrc/variants/liblegion_amd_unbounded.so
+#   bash profiles/ab_kernels.sh <outdir-under-gpurun_out> <absolute path of the variant .so> ["papers100M 25,10,5" "products 25,10,5" ...]
 O=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+VAR=$1; shift
+[ -f "$VAR" ] || { echo "variant library $VAR missing"; exit 1; }
 mkdir -p $O
-LIB=$GRAFT_REPO_ROOT/legion-1_amd/csrc/liblegion_amd.so
-cp $LIB $O/lib_new.so
 [ $# -eq 0 ] && set -- "papers100M 25,10,5" "products 25,10,5"
 WLS=("$@")
 cd /tmp && export TMPDIR=/tmp
 for round in 1 2; do
- for which in new old; do
-  if [ $which = old ]; then cp $GRAFT_REPO_ROOT/profiles/ab/liblegion_amd_old.so $LIB; else cp $O/lib_new.so $LIB; fi
+ for which in new var; do
+  if [ $which = var ]; then export LEGION_LIB=$VAR; else unset LEGION_LIB; fi
   for wl in "${WLS[@]}"; do
     set -- $wl
     rocprofv3 --kernel-trace --output-format csv -d $O/$which$round/$1 -- python3 $GRAFT_REPO_ROOT/bench.py --workload $1 --fanout $2 --headline-only --cpu-baseline-seconds 0 --measure-traffic off --extra-legs none --min-time 0.3 --steps 20 > $O/$which$round.$1.json 2>/dev/null || exit 1
@@ -35,4 +38,4 @@ PY
   done
  done
 done
-cp $O/lib_new.so $LIB
+unset LEGION_LIB

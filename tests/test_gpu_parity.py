@@ -320,6 +320,38 @@ def test_padded_row_pitch_gathers_the_same_bytes(K, oracle, synth, F, lanes, mon
     eng.close()
 
 
+def test_shard_geometry_travels_with_the_handles_and_a_mismatch_is_refused(K, small_ds):
+    """every process derives the shard pitch / chunk geometry from its own alpha and capacity, and an importer
+    addresses a peer's rows with ITS OWN.  The geometry travels next to the exported handles (Engine.export_shards) and
+    GPUCache_CheckShardGeometry refuses a shard that was built differently -- never a silent read at the wrong stride."""
+    import ctypes as C
+    ds = small_ds
+    L = K.lib()
+    eng = make_engine(K, ds, 300, [10, 5], G=2, train_step=2)
+    for g in range(2):
+        for it in range(2):
+            eng.run_batch(g, it, is_presc=True)
+    cap = ds.spec.V // 8
+    eng.build_cache(cache_agg_mode=1, node_capacity=cap, edge_capacity=0, train_step=2)
+    g4 = (C.c_int32 * 4)()
+    assert L.GPUCache_ShardGeometry(eng.cache, 0, g4) == 0
+    pitch, rows_per_chunk, nchunks, rows = list(g4)
+    assert pitch == L.GPUCache_ShardPitch(eng.cache) == L.legion_row_pitch(ds.spec.F) and rows == cap
+    assert rows_per_chunk == L.GPUCache_ShardChunkRows(eng.cache, 0) and nchunks == L.GPUCache_ShardChunkCount(eng.cache, 0)
+    assert eng.export_shards(0)[4] == (pitch, rows_per_chunk, nchunks, rows) == eng.export_shards(1)[4]
+    assert L.GPUCache_CheckShardGeometry(eng.cache, 1, g4) == 0 and not L.legion_last_error()
+    for k, bad in ((0, ds.spec.F), (1, rows_per_chunk // 2), (2, nchunks + 1), (3, rows + 1)):
+        wrong = (C.c_int32 * 4)(*g4)
+        wrong[k] = bad
+        assert L.GPUCache_CheckShardGeometry(eng.cache, 1, wrong) == -1
+        msg = L.legion_last_error().decode()
+        assert "refusing to import" in msg and "wrong stride" in msg and str(bad) in msg, msg
+        L.legion_clear_error()
+        with pytest.raises(RuntimeError, match="refusing to import"):      # ... and Engine.import_shards stops before it opens a handle
+            eng.import_shards(1, ([b"\0" * 64], None, None, (0, 0), tuple(wrong)))
+    eng.close()
+
+
 def test_launchers_refuse_bad_arguments_and_stay_usable(K, oracle, small_ds):
     """Argument errors of the boundary (sticky string, nothing launched, no exit) -- and the engine still produces the oracle's
     batch afterwards: a refusal must not leave half-updated host-side bounds behind."""

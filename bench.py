@@ -657,12 +657,12 @@ def served_consumer(argv):
 
 def served_schedule_windows(t, train_step, valid_step, epochs, K_steps, warm):
     """Windows of K consecutive TRAINING batches inside one epoch of the served schedule (CUDA_IPC_Service.cu:219-259: every epoch is
-    train_step training batches, then valid_step validation batches), the first `warm` training batches of epoch 0 left out: seconds per
+    train_step training batches, then valid_step validation batches), the first `warm` training batches of every epoch left out: seconds per
     window, measured arrival to arrival (t[i + K - 1] - t[i - 1]), and the global batch numbers each one covers."""
     per = train_step + valid_step
     out = []
     for e in range(epochs):
-        first = e * per + (warm if e == 0 else 0)
+        first = e * per + warm          # every epoch: the pipeline restarts behind the epoch's validation batches
         i = max(first, 1)
         while i + K_steps <= e * per + train_step:
             out.append((t[i + K_steps - 1] - t[i - 1], i))

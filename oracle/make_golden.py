@@ -147,6 +147,35 @@ def cache_fixture():
     return out
 
 
+PCM_FREE_CASE = dict(workload="products", batch=8000, fanout=[25, 10], presc_steps=8, budget_fracs=[0.10, 0.25, 0.60])
+
+
+def cost_model_pcm_free(case=PCM_FREE_CASE):
+    """The cache plan of a BASELINE shape WITHOUT the two Intel-PCM counters (counters == NULL: what the `legion` server of this repository
+    always passes) -- the transaction estimate `sum over ranked rows of edge hotness x ceil((8 + 4 min(deg, 16)) / 64)` replaced round 3's
+    "one transaction per sampled edge" and shifts alpha and both capacities for every such caller: this pins the numbers, so a
+    later edit of the weight is visible.  Full products shape, 8 pre-sampling batches of {25,10}, B = 8000, G = Kg = 1."""
+    spec = S.spec_for(case["workload"])
+    indptr, indices = O.synth_csr(spec)
+    B, fan, steps = case["batch"], case["fanout"], case["presc_steps"]
+    orc = O.OracleRunner(indptr, indices, None, spec.V, spec.F, B, fan, with_features=False)
+    train = S.seed_ids(spec, 0, spec.n_train)
+    labels = S.labels(spec, train)
+    max_ids = 0
+    for it in range(steps):
+        r = orc.run_batch(train, labels, it, is_presc=True, gather=False)
+        max_ids = max(max_ids, int(r["nc"][5 + 2 * len(fan)]))
+    AF, QF = O.candidate_selection([orc.node_access_time], spec.V)
+    AT, QT = O.candidate_selection([orc.edge_access_time], spec.V)
+    out = dict(case, V=spec.V, E=int(indptr[-1]), F=spec.F, max_ids=max_ids, node_hotness_sha256=sha(orc.node_access_time),
+               edge_hotness_sha256=sha(orc.edge_access_time), QF_sha256=sha(QF), QT_sha256=sha(QT), plans=[])
+    for frac in case["budget_fracs"]:
+        budget = int(spec.V * spec.F * 4 * frac)
+        cm = O.cost_model(AF, AT, QT, indptr, spec.V, spec.F, budget, 1, None, [max_ids], steps)
+        out["plans"].append(dict(budget_frac=frac, cache_memory=budget, **cm))
+    return out
+
+
 def lp_seed_lists():
     """Link-prediction seed lists ([src | pos | neg] thirds per batch, lp_sage.py:87-90) of synth.lp_trainingset: the 1-GPU list
     and the two lists of a 2-GPU job (triples dealt by src % 2).  Pins the on-disk layout of `trainingset` / `trainingset_<G>_<g>`."""
@@ -235,7 +264,8 @@ def main():
         print("wrote full_shape_digests", os.path.getsize(path), "bytes")
         return
     for name, fn in (("rng_kat", rng_kat), ("toy_batches", toy_cases), ("medium_digests", medium_digests),
-                     ("schedule_table", schedule_table), ("cache_fixture", cache_fixture), ("lp_seed_lists", lp_seed_lists)):
+                     ("schedule_table", schedule_table), ("cache_fixture", cache_fixture), ("lp_seed_lists", lp_seed_lists),
+                     ("cost_model_pcm_free", cost_model_pcm_free)):
         data = fn()
         with open(os.path.join(GOLD, name + ".json"), "w") as f:
             json.dump(data, f, separators=(",", ":"))

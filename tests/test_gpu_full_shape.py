@@ -400,3 +400,32 @@ def test_synth_server_serves_the_headline_shape(K, oracle, synth, tmp_path):
         for r0 in range(0, len(served_ids), 1 << 16):
             h.update(np.ascontiguousarray(synth.features(spec, served_ids[r0:r0 + (1 << 16)])).tobytes())
         assert rec["features"] == h.hexdigest(), rec["b"]
+
+
+def test_cost_model_without_pcm_counters_matches_the_golden_plan(K, synth):
+    """The product's cache plan at the full products shape with counters == NULL (the `legion` server's only mode: no Intel PCM) against
+    tests/golden/cost_model_pcm_free.json, which the oracle produced in the build container: pre-sampling hotness (SHA-256 of both u64[V]
+    arrays), max_ids, and per budget alpha and both capacities.  An edit of the transaction estimate's weight changes these numbers."""
+    from conftest import load_golden, sha
+    L = K.lib()
+    g = load_golden("cost_model_pcm_free")
+    spec, indptr, indices, feats, E = device_graph(K, synth, g["workload"])
+    assert (spec.V, E, spec.F) == (g["V"], g["E"], g["F"])
+    (ids, lab), = device_seeds(K, spec, 1)
+    n = int(ids.numel())
+    B, fan, steps = g["batch"], g["fanout"], g["presc_steps"]
+    for plan in g["plans"]:
+        eng = K.Engine(indptr.data_ptr(), indices.data_ptr(), feats.data_ptr(), spec.V, spec.F, dict(train=[((ids.data_ptr(), n), (lab.data_ptr(), n))]),
+                       B, fan, E=E, cache_memory=plan["cache_memory"], train_step=steps)
+        eng.alloc_features()
+        for it in range(steps):
+            eng.run_batch(0, it, is_presc=True)
+        assert L.GPUCache_MaxIdNum(eng.cache, 0) == g["max_ids"]
+        assert sha(K.read_dev(L.GPUCache_GetNodeAccessedMap(eng.cache, 0), np.uint64, spec.V)) == g["node_hotness_sha256"]
+        assert sha(K.read_dev(L.GPUCache_GetEdgeAccessedMap(eng.cache, 0), np.uint64, spec.V)) == g["edge_hotness_sha256"]
+        eng.build_cache(cache_agg_mode=0, counters=None, train_step=steps)
+        assert sha(K.read_dev(L.GPUCache_GetQF(eng.cache, 0), np.int32, spec.V)) == g["QF_sha256"]
+        assert sha(K.read_dev(L.GPUCache_GetQT(eng.cache, 0), np.int32, spec.V)) == g["QT_sha256"]
+        got = (L.GPUCache_NodeCapacity(eng.cache, 0), L.GPUCache_EdgeCapacity(eng.cache, 0), round(L.GPUCache_Alpha(eng.cache, 0) * 100))
+        assert got == (plan["node_capacity"], plan["edge_capacity"], plan["alpha_idx"]), (plan["budget_frac"], got)
+        eng.close()

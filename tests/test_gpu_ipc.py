@@ -188,7 +188,8 @@ def test_synchronize_with_queued_trainer_work(tmp_path, synth, oracle):
     sets = {0: ds.train, 1: ds.valid, 2: ds.test[:600]}
     steps, tb, vb, sb = oracle.coordinate([len(sets[0])], [len(sets[1])], [len(sets[2])], B)
     bs = {0: int(tb[0]), 1: int(vb[0]), 2: int(sb[0])}
-    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+    assert bs[2] > B and bs[1] > B          # evaluation batches LARGER than the training batch: the feature buffer is sized for them too
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, max(bs.values()), fan)
     assert len(got["batches"]) == oracle.max_step(steps, epochs) > 8
     for rec in got["batches"]:
         mode, local = oracle.schedule(steps, epochs, rec["b"])

@@ -303,3 +303,23 @@ def test_synth_spec_c_equals_python(synth):
         assert L.legion_synth_spec(name, scale, C.byref(bad)) == -1
         assert L.legion_last_error()
         L.legion_clear_error()
+
+
+def test_cost_model_pcm_free_golden_at_the_products_shape(oracle):
+    """the default cost-model input of this repository's server (counters == NULL: no Intel PCM) is an ESTIMATE --
+    sum over the ranked rows of edge hotness x ceil((8 + 4 min(deg, 16)) / 64) -- and every caller's alpha / capacities follow from it.
+    The plan at the full products shape (8 pre-sampling batches of {25,10}, three budgets) is pinned in tests/golden/cost_model_pcm_free.json
+    (`python oracle/make_golden.py`); the GPU suite checks the product against the same numbers (tests/test_gpu_full_shape.py)."""
+    import make_golden as M
+    g = load_golden("cost_model_pcm_free")
+    d = M.cost_model_pcm_free()
+    for k in ("V", "E", "F", "max_ids", "node_hotness_sha256", "edge_hotness_sha256", "QF_sha256", "QT_sha256"):
+        assert d[k] == g[k], k
+    assert len(d["plans"]) == len(g["plans"]) == 3
+    for a, b in zip(d["plans"], g["plans"]):
+        for k in ("cache_memory", "node_capacity", "edge_capacity", "alpha_idx"):
+            assert a[k] == b[k], (b["budget_frac"], k, a[k], b[k])
+        assert abs(a["best_trans"] - b["best_trans"]) <= 1e-6 * b["best_trans"]
+    # the plan moves with the budget the way a cost model should: more budget -> more feature rows, a smaller topology share
+    caps = [p["node_capacity"] for p in g["plans"]]
+    assert caps == sorted(caps) and [p["alpha_idx"] for p in g["plans"]] == sorted((p["alpha_idx"] for p in g["plans"]), reverse=True)

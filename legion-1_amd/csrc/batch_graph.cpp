@@ -56,12 +56,12 @@ int LegionBatchGraph_Launch(LegionBatchGraph* g, void* stream, int32_t counter)
     GPUMemoryPool* p = g->pool;
     if (p->capturing) { LEGION_ARG_ERROR("LegionBatchGraph_Launch: pool is being captured"); return -1; }
     hipStream_t s = (hipStream_t)stream;
-    if (++p->batch_serial >= 0xFFFFFFF0u) { // epoch space exhausted: wipe once and start over (as batch_generator_kernel)
-        HIP_CHECK(hipMemsetAsync(p->pos_map, 0xFF, (size_t)p->V * sizeof(unsigned long long), s));
+    if (++p->batch_serial >= kSerialLimit) { // epoch space exhausted: wipe once and start over (as batch_generator_kernel)
+        HIP_CHECK(hipMemsetAsync(p->pos_map, 0xFF, (size_t)p->V * sizeof(pos_t), s));
         p->batch_serial = 1;
         p->ctl_synced = false;
     }
-    if (!p->ctl_synced || p->ctl_counter != counter) launch_set_cursor(s, p->ctl, counter, 0xFFFFFFFFu - p->batch_serial);
+    if (!p->ctl_synced || p->ctl_counter != counter) launch_set_cursor(s, p->ctl, counter, kEpochTop - p->batch_serial);
     HIP_CHECK(hipGraphLaunch(g->exec, s));
     p->ctl_synced = true;     // k_advance left (counter + 1, next epoch) in ctl
     p->ctl_counter = counter + 1;

@@ -42,8 +42,23 @@ struct DeviceGuard {
 };
 
 // ---- constants --------------------------------------------------------------------------------
-constexpr uint32_t kUnseen = 0xFFFFFFFFu;      // position-table value: node not in the batch
-constexpr uint32_t kProvisional = 0x80000000u; // | slot idx : claimed in the running hop
+// Position-table entry: (epoch << kPosShift) | value.  epoch = kEpochTop - batch serial: entries of older batches compare GREATER than
+// anything of the running batch (stale without being touched); value = kProvisional | slot idx while claimed in the running hop, else
+// the node's final index in sampled_ids.  Default: u64 entries, 32-bit epoch (never wraps in practice).
+// -DLEGION_POS32 (experiment, profiles/r05_sampler.md): u32 entries -- 7-bit epoch, provisional flag, 24-bit value -- half the table
+// (889 -> 444 MB at the papers100M shape, 19.6 -> 9.8 MB at products), wiped every 126 batches; needs batch x prod(fan-outs) <= 2^24.
+#ifdef LEGION_POS32
+typedef uint32_t pos_t;
+constexpr int kPosShift = 25;
+constexpr uint32_t kProvisional = 1u << 24, kPosValueMask = 0x00FFFFFFu;
+constexpr uint32_t kEpochTop = 127u, kSerialLimit = 127u;
+#else
+typedef unsigned long long pos_t;
+constexpr int kPosShift = 32;
+constexpr uint32_t kProvisional = 0x80000000u, kPosValueMask = 0x7FFFFFFFu;
+constexpr uint32_t kEpochTop = 0xFFFFFFFFu, kSerialLimit = 0xFFFFFFF0u;
+#endif
+__host__ __device__ inline pos_t pos_entry(uint32_t epoch, uint32_t value) { return ((pos_t)epoch << kPosShift) | (pos_t)value; }
 #ifndef LEGION_KTILE
 #define LEGION_KTILE 1024
 #endif
@@ -123,7 +138,7 @@ struct SamplerBuffers {
     int32_t* agg_dst_off;   // IPC buffer 4
     int32_t* nc;            // IPC buffer 5
     int32_t* ec;            // IPC buffer 6
-    unsigned long long* pos_map; // u64[V]: (epoch << 32) | value
+    pos_t* pos_map;         // pos_t[V]: (epoch << kPosShift) | value
     const BatchCtl* ctl;    // ctl->epoch = 0xFFFFFFFF - batch serial: newer batches compare smaller
     int32_t* cand;          // i32[max slots of a hop]
     int32_t* aux;           // i32[max slots of a hop], slot state: -1 claim pending / won (k_mark: winner rank), >= 0 known position, <= -2 lost to slot -2-x
@@ -142,7 +157,7 @@ struct SamplerBuffers {
 };
 
 void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t batch_size, int32_t size, int32_t counter,
-                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
+                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, pos_t* pos_map,
                  uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec, int32_t* aux_next,
                  int32_t f_next, int32_t aux_cap);
 void launch_set_cursor(hipStream_t s, BatchCtl* ctl, int32_t counter, uint32_t epoch);
@@ -230,7 +245,7 @@ struct GPUMemoryPool {
     int32_t fanout[LEGION_MAX_HOPS] = {0};
     int32_t max_slots = 0, max_tiles = 0;
     int32_t feature_rows = 0;         // capacity of the feature buffers in rows (0 = unbounded)
-    unsigned long long* pos_map = nullptr; // u64[V], see kernels.hip "position table"
+    legion::pos_t* pos_map = nullptr; // pos_t[V], see kernels.hip "position table"
     uint32_t batch_serial = 0;        // batches started on this pool; epoch = 0xFFFFFFFF - serial
     legion::BatchCtl* ctl = nullptr;  // device copy of (batch cursor, epoch): what the kernels read
     // Feedback for sizing the gather launches without a host round trip: pinned, device-mapped words the gather

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
                                                  int32_t batch_size, int32_t size, int32_t counter,
                                                  const int32_t* __restrict__ all_ids,
                                                  const int32_t* __restrict__ all_labels, int32_t total_cap,
-                                                 unsigned long long* __restrict__ pos_map, uint32_t epoch,
+                                                 pos_t* __restrict__ pos_map, uint32_t epoch,
                                                  BatchCtl* __restrict__ ctl, int32_t* __restrict__ nc,
                                                  int32_t* __restrict__ ec, int32_t* __restrict__ aux_next,
                                                  int32_t f_next, int32_t aux_cap)
@@ -111,10 +111,10 @@ __global__ __launch_bounds__(kBlock) void k_seed(int32_t* __restrict__ batch_ids
             // position_map[src_id] = idx (Kernels.cu:92).  The reference assumes distinct seeds (:67); with
             // duplicates (link-prediction triples) its serial order lets the LAST occurrence win, so do the
             // same deterministically: the largest idx of the running epoch survives.
-            const unsigned long long mine = ((unsigned long long)epoch << 32) | (uint32_t)idx;
-            unsigned long long cur = pos_map[src_id];
-            while ((cur >> 32) != epoch || cur < mine) {
-                const unsigned long long seen = atomicCAS(pos_map + src_id, cur, mine);
+            const pos_t mine = pos_entry(epoch, (uint32_t)idx);
+            pos_t cur = pos_map[src_id];
+            while ((uint32_t)(cur >> kPosShift) != epoch || cur < mine) {
+                const pos_t seen = atomicCAS(pos_map + src_id, cur, mine);
                 if (seen == cur) break;
                 cur = seen;
             }
@@ -153,7 +153,7 @@ struct SampleArgs {
     const int32_t* agg_src_ids;
     const int32_t* nc;
     const int32_t* ec;
-    unsigned long long* pos_map;
+    pos_t* pos_map;
     int32_t* cand;
     int32_t* aux;
     int32_t* tile_edge;
@@ -268,31 +268,31 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                 } else {
                     // claim: lowest idx wins.  Entries of older batches have a larger epoch field, i.e. compare
                     // greater: unseen.  A stale (larger) pre-filter read only costs a redundant atomic.
-                    const unsigned long long prov0 = ((unsigned long long)epoch << 32) | kProvisional;
-                    const unsigned long long mine = prov0 | (uint32_t)idx;
+                    const pos_t prov0 = pos_entry(epoch, kProvisional);
+                    const pos_t mine = prov0 | (pos_t)(uint32_t)idx;
                     // (plain loads: a non-temporal hint on this pre-filter load costs +11 % of k_sample, on the neighbour load
                     // nothing, profiles/r02_sampler_experiments.md)
                     // hop 1: nearly every neighbour is new, so the pre-filter load would only add a dependent round trip in front
                     // of the claim -- go straight to the atomic (it returns the exact entry either way)
-                    unsigned long long cur = (a.op_id < a.prefilter_from_op) ? ~0ull : a.pos_map[dst];
+                    pos_t cur = (a.op_id < a.prefilter_from_op) ? ~(pos_t)0 : a.pos_map[dst];
                     if (cur > mine) {
-                        const unsigned long long old = atomicMin(a.pos_map + dst, mine);
+                        const pos_t old = atomicMin(a.pos_map + dst, mine);
                         if (old > mine) {
                             // the table holds this slot's claim now.  If it replaced a claim of this hop (a larger
                             // slot that got there first), that slot has lost for good: tell it who beat it.  Its own
                             // thread left aux at -1 (pending) and never writes it again, so this is the only store.
-                            if ((uint32_t)(old >> 32) == epoch) a.aux[(uint32_t)old & 0x7FFFFFFFu] = -2 - idx;
+                            if ((uint32_t)(old >> kPosShift) == epoch) a.aux[(uint32_t)old & kPosValueMask] = -2 - idx;
                             cur = mine;
                         } else {
                             cur = old; // a smaller entry arrived between the load and the atomic: exact value
                         }
                     }
                     // final positions are only written by earlier launches: if we see one it is exact
-                    if (cur < prov0) known = (int32_t)(uint32_t)cur;
+                    if (cur < prov0) known = (int32_t)((uint32_t)cur & kPosValueMask);
                     // a smaller claim of this hop is in the table: this slot has lost for good (claims only
                     // decrease).  Point at that slot; if it loses later too, its own aux points further, and
                     // k_write follows the chain to the winner.
-                    else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & 0x7FFFFFFFu);
+                    else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & kPosValueMask);
                 }
                 cnt++;
             }
@@ -467,7 +467,7 @@ struct WriteArgs {
     int32_t* agg_src_ids;
     int32_t* agg_src_off;
     int32_t* agg_dst_off;
-    unsigned long long* pos_map;
+    pos_t* pos_map;
     FastDiv fdiv;
     int32_t op_id;
     const BatchCtl* ctl;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
             const int32_t i = (int32_t)fdiv((uint32_t)idx, a.fdiv);
             // hop 1: the seed's position.  That is i unless the seed list holds duplicates (link-prediction
             // triples), where the reference's position_map keeps the last occurrence -- read it (<= B*f probes).
-            dpos[s] = (a.op_id == 2) ? (int32_t)(uint32_t)a.pos_map[a.sampled_ids[i]] : a.agg_src_off[h.in_off + i];
+            dpos[s] = (a.op_id == 2) ? (int32_t)((uint32_t)a.pos_map[a.sampled_ids[i]] & kPosValueMask) : a.agg_src_off[h.in_off + i];
             // lost the claim: first link of loser -> (earlier loser ->)* winner or known node
             // (with the in-chunk node prefix of that slot's tile, should it turn out to be the winner: same round trip)
             wpre[s] = 0;
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
                 p = nbase + win_rank(p);
                 if (LEGION_STORE_OK(p, a.ids_cap)) a.sampled_ids[p] = dst;
                 // the scattered table store is only needed when a later hop may look the node up by id
-                if (!a.last_hop && LEGION_STORE_OK(dst, a.V)) a.pos_map[dst] = ((unsigned long long)epoch << 32) | (uint32_t)p;
+                if (!a.last_hop && LEGION_STORE_OK(dst, a.V)) a.pos_map[dst] = pos_entry(epoch, (uint32_t)p);
             }
             a.agg_src_off[e] = p;
         }
@@ -1173,7 +1173,7 @@ static uint32_t* pow_table()
 }
 
 void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t batch_size, int32_t size, int32_t counter,
-                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, unsigned long long* pos_map,
+                 const int32_t* all_ids, const int32_t* all_labels, int32_t total_cap, pos_t* pos_map,
                  uint32_t epoch, BatchCtl* ctl, bool self_driven, int32_t* nc, int32_t* ec, int32_t* aux_next,
                  int32_t f_next, int32_t aux_cap)
 {

@@ -73,11 +73,11 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
     }
     // A new batch = a new epoch of the position table: entries of older batches become stale without
     // touching them (replaces cudaMemsetAsync(accessed_map) + ClearPosMap, Kernels.cu:216,750-756).
-    if (++p->batch_serial >= 0xFFFFFFF0u) { // epoch space exhausted: wipe once and start over
-        HIP_CHECK(hipMemsetAsync(p->pos_map, 0xFF, (size_t)p->V * sizeof(unsigned long long), s));
+    if (++p->batch_serial >= kSerialLimit) { // epoch space exhausted: wipe once and start over
+        HIP_CHECK(hipMemsetAsync(p->pos_map, 0xFF, (size_t)p->V * sizeof(pos_t), s));
         p->batch_serial = 1;
     }
-    const uint32_t epoch = 0xFFFFFFFFu - p->batch_serial;
+    const uint32_t epoch = kEpochTop - p->batch_serial;
     p->ctl_synced = false; // k_seed publishes (counter, epoch) of THIS batch: a batch graph must reset the cursor
     // Kernels.cu:224
     int32_t size = ((batch_size * (counter + 1)) >= total_cap) ? (total_cap - batch_size * counter) : batch_size;

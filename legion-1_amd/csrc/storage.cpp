@@ -555,11 +555,14 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     p->max_slots = (int32_t)max_slots;
     p->max_tiles = (int32_t)((max_slots + kTile - 1) / kTile);
     p->owns_scratch = true;
-    HIP_CHECK(hipMalloc(&p->pos_map, (size_t)total_num_nodes * sizeof(unsigned long long)));
-    HIP_CHECK(hipMemset(p->pos_map, 0xFF, (size_t)total_num_nodes * sizeof(unsigned long long)));
+#ifdef LEGION_POS32
+    if (max_slots > (int64_t)kPosValueMask || ids > (int64_t)kPosValueMask) { LEGION_ARG_ERROR("GPUMemoryPool_AllocateScratch: this -DLEGION_POS32 build holds 24-bit slot numbers / positions"); return; }
+#endif
+    HIP_CHECK(hipMalloc(&p->pos_map, (size_t)total_num_nodes * sizeof(pos_t)));
+    HIP_CHECK(hipMemset(p->pos_map, 0xFF, (size_t)total_num_nodes * sizeof(pos_t)));
     p->batch_serial = 0;
     HIP_CHECK(hipMalloc(&p->ctl, sizeof(BatchCtl)));
-    { const BatchCtl c{0, 0xFFFFFFFFu}; HIP_CHECK(hipMemcpy(p->ctl, &c, sizeof(c), hipMemcpyHostToDevice)); }
+    { const BatchCtl c{0, kEpochTop}; HIP_CHECK(hipMemcpy(p->ctl, &c, sizeof(c), hipMemcpyHostToDevice)); }
     p->ctl_synced = false;
     HIP_CHECK(hipHostMalloc((void**)&p->rows_seen, (LEGION_MAX_HOPS + 2) * sizeof(int32_t), hipHostMallocMapped));
     memset(p->rows_seen, 0, (LEGION_MAX_HOPS + 2) * sizeof(int32_t));

@@ -16,8 +16,9 @@ for round in 1 2; do
   if [ $which = var ]; then export LEGION_LIB=$VAR; else unset LEGION_LIB; fi
   for wl in "${WLS[@]}"; do
     set -- $wl
-    rocprofv3 --kernel-trace --output-format csv -d $O/$which$round/$1 -- python3 $GRAFT_REPO_ROOT/bench.py --workload $1 --fanout $2 --headline-only --cpu-baseline-seconds 0 --measure-traffic off --extra-legs none --min-time 0.3 --steps 20 > $O/$which$round.$1.json 2>/dev/null || exit 1
-    python3 - $O/$which$round/$1 "$which$round $1 $2" $O/$which$round.$1.json <<'PY'
+    D=$1_${2//,/-}      # one trace directory per (workload, fan-out)
+    rocprofv3 --kernel-trace --output-format csv -d $O/$which$round/$D -- python3 $GRAFT_REPO_ROOT/bench.py --workload $1 --fanout $2 --headline-only --cpu-baseline-seconds 0 --measure-traffic off --extra-legs none --min-time 0.3 --steps 20 > $O/$which$round.$D.json 2>/dev/null || exit 1
+    python3 - $O/$which$round/$D "$which$round $1 $2" $O/$which$round.$D.json <<'PY'
 import csv, glob, collections, statistics, sys, json
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 seq = []

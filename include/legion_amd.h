@@ -425,6 +425,9 @@ int IPCEnv_SlabPinned(IPCEnv* e);   /* 1: the slab is page-locked (hipHostRegist
 void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int IPCEnv_IPCTryWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t timeout_ms); /* 0 = acquired */
+/* Both sides poll the semaphore for $LEGION_HANDOFF_SPIN_US microseconds (default 200; 0 = block at once) before they block on it: a futex
+ * wake-up costs 10-60 us and sits on the depth-2 handshake of every batch (profiles/r05_handoff_spin.md). */
+int IPCEnv_HandoffSpinUs(void);
 void IPCEnv_Finalize(IPCEnv* e);
 int32_t IPCEnv_GetTrainStep(IPCEnv* e);
 /* extension: number of hops published to the trainer (stored after the reference's struct) */

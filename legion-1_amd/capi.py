@@ -220,6 +220,7 @@ _SIGS = {
     "IPCEnv_GetEdgeCounter": (vp, [vp, i32, i32]),
     "IPCEnv_IPCPost": (None, [vp, i32, i32]), "IPCEnv_IPCWait": (None, [vp, i32, i32]),
     "IPCEnv_IPCTryWait": (C.c_int, [vp, i32, i32, i32]),
+    "IPCEnv_HandoffSpinUs": (C.c_int, []),
     "IPCEnv_Finalize": (None, [vp]), "IPCEnv_GetTrainStep": (i32, [vp]), "IPCEnv_SetHops": (None, [vp, i32]),
     "legion_ipc_set_namespace": (None, [C.c_char_p]),
     "legion_ipc_client_open": (vp, [i32]), "legion_ipc_client_wait": (None, [vp]),

@@ -59,6 +59,35 @@ static bool no_device()
 }
 #define LEGION_DEVICE_GUARD(dev) std::optional<DeviceGuard> guard_; if (!no_device()) guard_.emplace(dev)
 
+// Waiting for the other side of the hand-off: poll the semaphore for a bounded time before blocking on it.  A blocked waiter is woken
+// through the kernel (futex) -- 10-60 us on an idle core -- and that latency sits on the depth-2 handshake of every batch: the server may only
+// refill a pipe after the trainer has handed it back.  $LEGION_HANDOFF_SPIN_US (default 200; 0 = block at once, rounds 1-4): how long a
+// waiter polls first.  A trainer that is the bottleneck costs the server at most that much polling per batch, then it sleeps as before.
+static int handoff_spin_us()
+{
+    static const int v = [] { const char* e = getenv("LEGION_HANDOFF_SPIN_US"); const int x = e ? atoi(e) : 200; return x < 0 ? 0 : (x > 100000 ? 100000 : x); }();
+    return v;
+}
+static inline int64_t mono_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
+// sem_wait with a polling prologue; EINTR-safe
+static void sem_wait_spin(sem_t* sem)
+{
+    const int spin = handoff_spin_us();
+    if (spin > 0) {
+        const int64_t until = mono_ns() + (int64_t)spin * 1000;
+        do {
+            if (sem_trywait(sem) == 0) return;
+            for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+        } while (mono_ns() < until);
+    }
+    while (sem_wait(sem) != 0 && errno == EINTR) {}
+}
+
 static std::string g_namespace;
 static bool g_ns_init = false;
 static const std::string& ipc_ns()
@@ -529,10 +558,15 @@ void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
 {
     sem_t* sem = e->semr[dev_id][current_pipe % e->pipeline_depth];
     if (!sem) return;      // sem_open failed (sticky error): never block on a semaphore that does not exist
-    while (sem_wait(sem) != 0 && errno == EINTR) {}
+    sem_wait_spin(sem);
 }
+int IPCEnv_HandoffSpinUs(void) { return handoff_spin_us(); }
 int IPCEnv_IPCTryWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t timeout_ms)
 {
+    if (timeout_ms <= 0) {     // a pure poll: no clock, no syscall beyond the futex word
+        sem_t* sem0 = e->semr[dev_id][current_pipe % e->pipeline_depth];
+        return (sem0 && sem_trywait(sem0) == 0) ? 0 : -1;
+    }
     struct timespec ts;
     clock_gettime(CLOCK_REALTIME, &ts);
     ts.tv_sec += timeout_ms / 1000;
@@ -720,7 +754,7 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
 
 void legion_ipc_client_wait(LegionIPCClient* c)
 {
-    while (sem_wait(c->semw[c->current_pipe]) != 0 && errno == EINTR) {}
+    sem_wait_spin(c->semw[c->current_pipe]);
 }
 // Post(): the pipe's buffers go back to the server, which overwrites them with batch i + 2.  The reference's trainer never
 // synchronises its device around synchronize() (legion_graphsage.py:93-116): what bounded its run-ahead was the BLOCKING counter copy of

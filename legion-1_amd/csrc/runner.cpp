@@ -173,6 +173,11 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     if (r->pending) {
         // Pipelined loop: batch i-1 is in flight.  Wait for the trainer to free this pipe, but hand batch i-1 over
         // the moment it is complete -- a trainer that is the bottleneck must not wait for our next enqueue.
+        // Poll first ($LEGION_HANDOFF_SPIN_US, default 200 us): the trainer usually frees the pipe within tens of microseconds of the post at the
+        // end of the previous RunOnce, and a sleep_for(10 us) really sleeps 60+ us (timer slack) -- on the critical chain of every batch
+        // (gather i-1 done -> post -> trainer -> pipe free -> sampler i+1 may start).  After the polling budget: sleep between looks, as before.
+        const auto t_wait = std::chrono::steady_clock::now();
+        const auto spin = std::chrono::microseconds(IPCEnv_HandoffSpinUs());
         while (IPCEnv_IPCTryWait(env, r->local_dev_id, r->current_pipe, 0) != 0) {
             if (hipEventQuery(r->done_ev[r->pending_pipe]) == hipSuccess) {
                 IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
@@ -180,7 +185,8 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
                 IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
                 break;
             }
-            std::this_thread::sleep_for(std::chrono::microseconds(10));
+            if (std::chrono::steady_clock::now() - t_wait < spin) { for (int i = 0; i < 64; i++) __builtin_ia32_pause(); }
+            else std::this_thread::sleep_for(std::chrono::microseconds(10));
         }
     } else {
         IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Experiment helper (profiles/r05_sampler.md): a -DLEGION_POS32 variant library wipes its u32 position table every 126 batches.
+"""Checker of an experiment (profiles/r05_sampler.md; lives under tests/ because it uses the oracle): a -DLEGION_POS32 variant library wipes its u32 position table every 126 batches.
 400 consecutive batches on one pool against the oracle, word for word: three wipes, every epoch value used.
-    LEGION_LIB=$PWD/legion-1_amd/csrc/variants/liblegion_amd_pos32.so python3 profiles/pos32_wrap_check.py"""
+    LEGION_LIB=$PWD/legion-1_amd/csrc/variants/liblegion_amd_pos32.so python3 tests/pos32_wrap_check.py"""
 import os
 import sys
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]   # tests/ = this directory (conftest)
 import legion1_amd.capi as K  # noqa: E402
 import legion1_amd.synth as S  # noqa: E402
 import oracle as O  # noqa: E402

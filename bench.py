@@ -873,8 +873,13 @@ def run_leg(c, unified, headline, min_time=None, with_alt=False):
         stream = L.d_stream_create_priority(1 if args.stream_priority == "sampler" else 0)
         gstream2 = L.d_stream_create_priority(1 if args.stream_priority == "gather" else 0)
     else:
-        stream = L.d_stream_create()       # sampler stream
-        gstream2 = L.d_stream_create()     # gather stream of the overlapped schedule (reference: streams_[1], Server.cu:178-181)
+        # ONE pair of streams per process, shared by every leg.  HIP maps streams onto a few hardware queues; a leg that created its own pair
+        # could land both streams on one queue, depending on how many streams earlier legs had created -- its two-stream schedules then ran
+        # SLOWER than the serial one (products {25,10} directly behind the headline: overlap 0.283 / levels 0.317 ms against 0.233 / 0.245 ms
+        # behind another leg, profiles/r05_stream_pair.md).  The first two streams of a process are what the `legion` runner uses, too.
+        if getattr(c, "stream_pair", None) is None:
+            c.stream_pair = (L.d_stream_create(), L.d_stream_create())
+        stream, gstream2 = c.stream_pair   # sampler stream; gather stream of the overlapped schedule (reference: streams_[1], Server.cu:178-181)
     steps_avail = c.steps_avail
     K_steps, W = args.steps, args.warmup
 

@@ -37,6 +37,13 @@ struct Runner {
     // host enqueues batch i and only then waits for batch i-1 and posts its pipe, so the sampler of batch i
     // (stream 0) overlaps the gathers of batch i-1 (stream 1) on the GPU.
     bool pipelined = true;
+    // $LEGION_RUNNER_GATHER = auto (default) | level | all.  level: one FeatureExtractor op per level on stream 1 behind each hop (the reference's
+    // op list, Server.cu:198-207).  all: ONE gather over all rows behind the last hop (get_feature_kernel_all).  Same bytes in the same buffer.
+    // Which is faster depends on the shape (profiles/r05_runner_gather.md, served batches, same box): when the gather outweighs the sampler the
+    // single launch wins (papers100M {25,10,5} -2.8 %, products {25,10} -4 %), when the sampler outweighs it the per-level gathers hide behind the
+    // long hops (products {25,10,5}: `all` +5.7 %).  auto decides once, after the pre-sampling epoch, from the last pre-sampled batch's counters.
+    bool gather_all = false;
+    bool gather_auto = true;
     bool pending = false;
     int pending_pipe = 0;
     hipEvent_t done_ev[LEGION_PIPELINE_DEPTH] = {};
@@ -80,6 +87,7 @@ void Runner_Initialize(Runner* r, RunnerParams* params)
     r->pipeline_depth = LEGION_PIPELINE_DEPTH;
     { const char* e = getenv("LEGION_BATCH_GRAPH"); r->graph_mode = e ? atoi(e) : 0; r->use_graph = r->graph_mode != 0; }
     { const char* e = getenv("LEGION_RUNNER_PIPELINE"); r->pipelined = !(e && atoi(e) == 0); }
+    { const char* e = getenv("LEGION_RUNNER_GATHER"); r->gather_all = e && strcmp(e, "all") == 0; r->gather_auto = !e || strcmp(e, "auto") == 0; }
     for (auto& ev : r->done_ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int total_num_nodes = GPUNodeStorage_TotalNodeNum(noder);
     GPUCache_InitializeCacheController(cache, r->local_dev_id, total_num_nodes);
@@ -140,6 +148,30 @@ void Runner_InitializeFeaturesBuffer(Runner* r, RunnerParams* params)
     }
     if (num_ids > r->num_ids) num_ids = r->num_ids;
     if (num_ids < 1) num_ids = r->num_ids;
+    if (r->gather_auto) {
+        // One-off estimate from the last batch of the pre-sampling epoch (its counters are still in pipe 0): sampler ~ 45 ps per slot (the
+        // memory system's random-access rate: 54 ps at papers100M, 43 ps at products {25,10,5}), gather ~ rows x (8F + 8) bytes at 6 TB/s
+        // (5.2 TB/s for rows that are not whole 128-byte lines).  A wrong guess costs a few per cent, never correctness.
+        int32_t nc[16] = {0}, ec[16] = {0};
+        const int32_t* dnc = IPCEnv_GetNodeCounter(env, r->local_dev_id, 0);
+        const int32_t* dec = IPCEnv_GetEdgeCounter(env, r->local_dev_id, 0);
+        if (dnc && dec && hipMemcpy(nc, dnc, sizeof(nc), hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(ec, dec, sizeof(ec), hipMemcpyDeviceToHost) == hipSuccess) {
+            const int H = r->hops;
+            double slots = 0.0, n_in = (double)nc[4];
+            for (int h = 1; h <= H; h++) {
+                slots += n_in * (double)params->fanout[h - 1];
+                n_in = (double)(ec[2 + h] - (h > 1 ? ec[2 + h - 1] : 0));     // edges of hop h = input of hop h + 1
+            }
+            const double rows = (double)GPUCache_MaxIdNum(cache, r->local_dev_id);
+            const int F = r->float_attr_len;
+            const double gather_us = rows * (8.0 * F + 8.0) / (((F * 4) % 128 == 0) ? 6.0e6 : 5.2e6), sampler_us = slots * 45e-6;
+            r->gather_all = gather_us > sampler_us;
+            log_out() << r->local_dev_id << " Runner gather: " << (r->gather_all ? "one launch over all rows behind the last hop" : "per level behind each hop")
+                      << " (estimated gather " << (int)gather_us << " us, sampler " << (int)sampler_us << " us per batch)\n";
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     r->feature_rows = (int32_t)num_ids;
     IPCEnv_InitializeFeaturesBuffer(env, 0, (int32_t)num_ids, r->float_attr_len, r->local_dev_id, r->pipeline_depth);
     for (int i = 0; i < r->pipeline_depth; i++)
@@ -213,10 +245,17 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         GPUMemoryPool_SetCurrentPipe(r->memorypool, r->current_pipe);
     };
     auto run_ops = [&]() {
+        const int last_feat = 2 * r->hops + 1;           // the FeatureExtractor behind the last hop
         for (int i = 0; i < r->op_num; i++) {
+            if (r->gather_all && (i & 1) && i < last_feat) continue;
             if (i % 2 == 1) HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[i - 1], 0));
             r->op_params[i]->is_presc = 0;
-            Operator_run(r->op_factory[i], r->op_params[i]);
+            if (r->gather_all && i == last_feat) {
+                OpParams* fp = r->op_params[i];
+                get_feature_kernel_all(r->streams[1], (GPUCache*)fp->cache, (GPUNodeStorage*)fp->noder, r->memorypool, fp->device_id, fp->in_memory);
+            } else {
+                Operator_run(r->op_factory[i], r->op_params[i]);
+            }
         }
     };
     if (r->use_graph && r->mode >= 0 && r->mode < 3) {

@@ -89,9 +89,9 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
     assert ("Tables stay in pinned host memory" if tables == "host" else "Tables replicated into HBM") in text
 
 
-@pytest.mark.parametrize("workload,scale,fan,B,G", [("products", 0.004, [5, 4, 3], 512, 1), ("papers100M", 0.0008, [25, 10], 1000, 1),
-                                                   ("uk-union", 0.0005, [10, 5], 512, 2)])
-def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, fan, B, G):
+@pytest.mark.parametrize("workload,scale,fan,B,G,gather", [("products", 0.004, [5, 4, 3], 512, 1, "auto"), ("papers100M", 0.0008, [25, 10], 1000, 1, "level"),
+                                                          ("uk-union", 0.0005, [10, 5], 512, 2, "all"), ("products", 0.004, [25, 10, 5], 512, 1, "auto")])
+def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, fan, B, G, gather):
     """meta_config dataset path `synth:<workload>:<scale>`: the server generates CSR + features in HBM with the legion_synth_* calls
     (no files) -- what bench.py's `served` leg starts at the papers100M shape.  Every served batch (train, valid, test) must equal the
     oracle run on the numpy statement of the same generator; G = 2: two logical GPUs, one trainer each, tid % G seed split."""
@@ -101,8 +101,10 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
         f.write("synth:%s:%r %d %d %d %d %d %d %d %d %d 0" % (workload, scale, B, spec.V, ds.E, spec.F, spec.n_train, n_valid, n_test, 1 << 40, epochs))
-    ns = "sy%d_%s_" % (os.getpid(), workload[:2])
-    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ns = "sy%d_%s%d_" % (os.getpid(), workload[:2], len(fan) + fan[0])
+    # LEGION_RUNNER_GATHER: one FeatureExtractor op per level (the reference's op list) / one gather over all rows behind the last hop /
+    # auto = decided once after the pre-sampling epoch from its counters -- the served batches are the same bytes either way
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_RUNNER_GATHER=gather)
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:
         server = subprocess.Popen([SERVER, str(G), "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=str(tmp_path))
@@ -126,6 +128,7 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
             server.kill()
     text = open(log).read()
     assert "Graph generated in HBM: %d edges" % ds.E in text and "Tables generated in HBM" in text and "Server Stopped" in text
+    assert ("Runner gather:" in text) == (gather == "auto")
     H = len(fan)
     parts = {0: oracle.split_seeds(ds.train, G), 1: oracle.split_seeds(ds.valid[:n_valid], G), 2: oracle.split_seeds(ds.test[:n_test], G)}
     steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)

@@ -53,10 +53,22 @@ def main():
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--variants", default="all", help="comma list of: reference loop,pipelined,hipGraph,fork/join graph,graph + gather")
     ap.add_argument("--full-eval", action="store_true", help="keep the full validation / test sets (512-seed batches)")
+    ap.add_argument("--source", default="files", choices=["files", "synth"],
+                    help="files: write the dataset in Legion's raw layout and let the server read it (GPUGraphStore.cu:254-325).  synth: the server generates "
+                         "the same tables in its own HBM (meta_config dataset path `synth:<workload>:<scale>`) -- the only way to serve the papers100M / uk-union shapes")
     a = ap.parse_args()
     if a.consume:
         return consume(a.consume, len(a.fanout.split(",")))
     import legion1_amd.synth as S
+    if a.source == "synth":
+        spec = S.spec_for(a.workload, scale=a.scale)
+        n_eval = min(512, spec.n_valid, spec.n_test) if not a.full_eval else None
+        tmp = tempfile.mkdtemp(prefix="legion_serve_")
+        meta = os.path.join(tmp, "meta_config")
+        with open(meta, "w") as f:
+            f.write("synth:%s:%r %d %d 0 %d %d %d %d 0 %d 0" % (a.workload, a.scale, a.batch, spec.V, spec.F, spec.n_train,
+                                                             n_eval or spec.n_valid, n_eval or spec.n_test, a.epochs))
+        return serve_variants(a, tmp, meta)
     ds = S.generate(S.spec_for(a.workload, scale=a.scale))
     if not a.full_eval:   # keep the schedule dominated by full training batches: one validation / test batch each
         import dataclasses
@@ -68,6 +80,10 @@ def main():
     meta = os.path.join(tmp, "meta_config")
     with open(meta, "w") as f:
         f.write(S.meta_config_line(ds, data, a.batch, 1 << 40, a.epochs, 0))
+    return serve_variants(a, tmp, meta)
+
+
+def serve_variants(a, tmp, meta):
     server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
     variants = [("reference loop", {"LEGION_RUNNER_PIPELINE": "0"}), ("pipelined", {}), ("hipGraph", {"LEGION_BATCH_GRAPH": "1"}),
                 ("fork/join graph", {"LEGION_BATCH_GRAPH": "2"}), ("graph + gather", {"LEGION_BATCH_GRAPH": "3"}), ("pipelined", {}),

@@ -146,6 +146,36 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
             assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
 
 
+def test_server_log_goes_to_stderr_on_request(tmp_path, synth):
+    """$LEGION_LOG=stderr: every progress print of the library (the reference prints to stdout: "Train Steps", "Storage Initialized", "System is
+    ready for serving" ...) goes to stderr, for a host that owns stdout (bench.py's one JSON line); unset: stdout, like the reference."""
+    spec = synth.spec_for("products", scale=0.004)
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write("synth:products:0.004 128 %d 0 %d %d 10 10 0 1 0" % (spec.V, spec.F, spec.n_train))
+    for log_env, where in (("stderr", "stderr"), (None, "stdout")):
+        env = dict(os.environ, LEGION_IPC_NAMESPACE="lg%d_%s_" % (os.getpid(), where), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("LEGION_LOG", None)
+        if log_env:
+            env["LEGION_LOG"] = log_env
+        fo, fe = str(tmp_path / ("out_" + where)), str(tmp_path / ("err_" + where))
+        with open(fo, "w") as o, open(fe, "w") as e:
+            server = subprocess.Popen([SERVER, "1", "0", "5,4", meta], stdout=o, stderr=e, env=env, cwd=str(tmp_path))
+        try:
+            _wait_ready(server, fe if where == "stderr" else fo)
+            client = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ipc_client_plain.py"), str(spec.F), "1", str(tmp_path / "c.json"), "0"],
+                                    env=env, capture_output=True, text=True, timeout=300)
+            assert client.returncode == 0, client.stdout[-1500:] + client.stderr[-1500:]
+            server.wait(timeout=120)
+        finally:
+            if server.poll() is None:
+                server.kill()
+        out, err = open(fo).read(), open(fe).read()
+        text, other = (err, out) if where == "stderr" else (out, err)
+        assert "Train Steps:" in text and "System is ready for serving" in text and "Server Stopped" in text, (where, out[-800:], err[-800:])
+        assert "Train Steps:" not in other and "ready for serving" not in other, (where, other[-800:])
+
+
 def test_server_synth_dataset_source_refuses_a_wrong_meta_line(tmp_path, synth):
     """V / F / E / seed-set sizes of the meta line that are not the generator's: the server stops with an error, no trainer is ever posted."""
     spec = synth.spec_for("products", scale=0.004)

@@ -97,7 +97,8 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
     oracle run on the numpy statement of the same generator; G = 2: two logical GPUs, one trainer each, tid % G seed split."""
     spec = synth.spec_for(workload, scale=scale)
     ds = synth.generate(spec)
-    epochs, n_valid, n_test = 2, min(700, spec.n_valid), min(300, spec.n_test)     # the meta line takes the first n ids of each range
+    epochs = int(os.environ.get("LEGION_TEST_EPOCHS", "2"))                          # soak: LEGION_TEST_EPOCHS=60
+    n_valid, n_test = min(700, spec.n_valid), min(300, spec.n_test)                   # the meta line takes the first n ids of each range
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
         f.write("synth:%s:%r %d %d %d %d %d %d %d %d %d 0" % (workload, scale, B, spec.V, ds.E, spec.F, spec.n_train, n_valid, n_test, 1 << 40, epochs))

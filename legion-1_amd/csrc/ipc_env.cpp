@@ -356,6 +356,12 @@ static void pin_slab(IPCEnv* e)
 void IPCEnv_Coordinate(IPCEnv* e, const LegionBuildInfo* info)
 {
     if (!e || !info) { LEGION_ARG_ERROR("IPCEnv_Coordinate: null argument"); return; }
+    if (info->partition_count < 1 || info->partition_count > e->device_count || info->raw_batch_size < 1 || info->epoch < 0 ||
+        !info->training_set_num || !info->validation_set_num || !info->testing_set_num) {
+        // the reference divides by raw_batch_size unchecked (CUDA_IPC_Service.cu:89)
+        LEGION_ARG_ERROR("IPCEnv_Coordinate: partition_count must be 1..device_count, raw_batch_size >= 1, epoch >= 0, the three size arrays non-null");
+        return;
+    }
     const int32_t P = info->partition_count;
     e->epoch = info->epoch;
     e->raw_batch_size = info->raw_batch_size;

@@ -527,6 +527,24 @@ void Server_Initialize(Server* s, int global_shard_count)
                   << "\nValidation set num: " << m.validation_set_num << "\nTesting set num:    " << m.testing_set_num
                   << "\nCache memory:       " << m.cache_memory << "\nTrain epoch:        " << m.epoch
                   << "\nPartition?:         " << m.partition << "\n";
+        // The reference reads the eleven fields unchecked (GPUGraphStore.cu:190-223): a short or mistyped line leaves zeros behind and the
+        // first division by the batch size or the first zero-byte table ends the server without a message.  Refuse it here, by name.
+        const char* bad = nullptr;
+        if (iss.fail()) bad = "fewer than eleven fields (path batch V E F n_train n_valid n_test cache_bytes epochs partition_flag)";
+        else if (m.raw_batch_size < 1) bad = "batch size < 1";
+        else if (m.node_num < 1) bad = "node count < 1";
+        else if (m.edge_num < 0) bad = "negative edge count";
+        else if (m.float_attr_len < 1) bad = "feature dim < 1";
+        else if (m.training_set_num < 0 || m.validation_set_num < 0 || m.testing_set_num < 0) bad = "negative seed-set size";
+        else if (m.training_set_num > m.node_num || m.validation_set_num > m.node_num || m.testing_set_num > m.node_num) bad = "a seed set larger than the node count";
+        else if (m.cache_memory < 0) bad = "negative cache budget";
+        else if (m.epoch < 0) bad = "negative epoch count";
+        else if (m.partition < 0 || m.partition > 2) bad = "partition flag outside 0..2";
+        if (bad) {
+            const std::string msg = std::string("Server_Initialize: meta_config refused: ") + bad;
+            LEGION_ARG_ERROR(msg.c_str());
+            return;
+        }
     }
     const int32_t V = m.node_num;
     const int32_t F = m.float_attr_len;

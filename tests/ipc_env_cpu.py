@@ -85,6 +85,11 @@ def producer(ns):
     L.IPCEnv_InitializeSamplesBuffer(e, 500, 1000, 16, 9, 2)    # device outside the env: refused, nothing touched
     assert b"InitializeSamplesBuffer: bad arguments" in L.legion_last_error()
     L.legion_clear_error()
+    bad = K.LegionBuildInfo()                                   # the reference divides by raw_batch_size unchecked (CUDA_IPC_Service.cu:89)
+    bad.partition_count, bad.epoch, bad.raw_batch_size = N_DEV, 2, 0
+    L.IPCEnv_Coordinate(e, C.byref(bad))
+    assert b"IPCEnv_Coordinate: partition_count must be" in L.legion_last_error()
+    L.legion_clear_error()
     info = K.LegionBuildInfo()
     nums = [(C.c_int32 * N_DEV)(3601, 4000), (C.c_int32 * N_DEV)(700, 650), (C.c_int32 * N_DEV)(300, 10)]
     info.partition_count, info.epoch, info.raw_batch_size = N_DEV, 2, 500

@@ -323,3 +323,28 @@ def test_cost_model_pcm_free_golden_at_the_products_shape(oracle):
     # the plan moves with the budget the way a cost model should: more budget -> more feature rows, a smaller topology share
     caps = [p["node_capacity"] for p in g["plans"]]
     assert caps == sorted(caps) and [p["alpha_idx"] for p in g["plans"]] == sorted((p["alpha_idx"] for p in g["plans"]), reverse=True)
+
+
+def test_server_binary_refuses_a_malformed_meta_config(tmp_path):
+    """The `legion` binary against meta_config lines the reference would read unchecked (GPUGraphStore.cu:190-223: a short line leaves zeros
+    behind; the first division by the batch size ends the process without a message).  Refused by name, exit code 1, before any device call --
+    so this runs in the build container."""
+    import subprocess
+    server = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "legion-1_amd", "csrc", "legion")
+    assert os.path.exists(server), "build the server: make -C legion-1_amd/csrc legion"
+    cases = [("garbage", "fewer than eleven fields"), ("/d/ 8000 100 1000 16 10 10 10 0 1", "fewer than eleven fields"),
+             ("/d/ 0 100 1000 16 10 10 10 0 1 0", "batch size < 1"), ("/d/ 8 0 1000 16 10 10 10 0 1 0", "node count < 1"),
+             ("/d/ 8 100 -5 16 10 10 10 0 1 0", "negative edge count"), ("/d/ 8 100 1000 0 10 10 10 0 1 0", "feature dim < 1"),
+             ("/d/ 8 100 1000 16 -1 10 10 0 1 0", "negative seed-set size"), ("/d/ 8 100 1000 16 101 10 10 0 1 0", "larger than the node count"),
+             ("/d/ 8 100 1000 16 10 10 10 -1 1 0", "negative cache budget"), ("/d/ 8 100 1000 16 10 10 10 0 -2 0", "negative epoch count"),
+             ("/d/ 8 100 1000 16 10 10 10 0 1 3", "partition flag outside 0..2"), ("synth:nothing 8 100 0 16 10 10 10 0 1 0", "names no known workload")]
+    for line, want in cases:
+        meta = tmp_path / "meta_config"
+        meta.write_text(line)
+        r = subprocess.run([server, "1", "0", "5,4", str(meta)], capture_output=True, text=True, timeout=60, cwd=str(tmp_path),
+                           env=dict(os.environ, LEGION_IPC_NAMESPACE="badmeta%d_" % os.getpid()))
+        assert r.returncode == 1 and want in r.stderr and "ready for serving" not in r.stdout, (line, r.returncode, r.stderr[-400:])
+    r = subprocess.run([server, "1", "0", "5,4", str(tmp_path / "missing")], capture_output=True, text=True, timeout=60, cwd=str(tmp_path))
+    assert r.returncode == 1 and "meta_config missing" in r.stderr
+    r = subprocess.run([server], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage:" in r.stderr

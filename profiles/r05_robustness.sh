@@ -2,7 +2,7 @@
 # Host-side sanitizer run of the product: liblegion_amd built with AddressSanitizer + UBSan on every HOST object
 # (make -C legion-1_amd/csrc asan-host; device code untouched), selected through $LEGION_LIB, on the CPU-reachable subset of the suite in the
 # BUILD CONTAINER (no GPU): the NULL / out-of-range argument walk over the C ABI, the host logic (shard pitch, client-open refusals, the
-# synth spec, the cost-model host path), the symbol table, and the slab / semaphore / mirror / poisoned-pipe protocol of ipc_env.cpp with a
+# synth spec, the server binary's meta_config parsing and refusals), the symbol table, and the slab / semaphore / mirror / poisoned-pipe protocol of ipc_env.cpp with a
 # fake producer and two fake consumer processes.   bash profiles/r05_robustness.sh > profiles/r05_robustness.log 2>&1
 set -u
 cd "$(dirname "$0")/.."
@@ -37,6 +37,7 @@ if grep -q "AddressSanitizer: heap-buffer-overflow" /tmp/r05_asan_control.txt &&
 else echo "   CONTROL FAILED: the sanitizer did not report the overflow"; rc=1; fi
 echo "== 1. tests/abi_null_args.py"; python tests/abi_null_args.py | tail -n 3 || rc=1
 echo "== 2. tests/ipc_env_cpu.py (producer + 2 consumers + poisoned pipe + stale semaphores)"; python tests/ipc_env_cpu.py producer "rb$$_" | grep PRODUCER_OK || rc=1
+export LEGION_SERVER_BIN=$PWD/legion-1_amd/csrc/asan/legion_asan      # the server binary itself under the sanitizers: argv + meta_config parsing and refusals
 echo "== 3. pytest: host logic, symbol table, IPC env on the CPU, oracle-vs-host-side comparisons"
 python -m pytest tests/test_host_logic.py tests/test_capi_symbols.py tests/test_ipc_env_cpu.py -q -p no:cacheprovider 2>&1 | tail -n 6 || rc=1
 echo "== apart from the control in step 0, 'ERROR: AddressSanitizer' / 'runtime error:' must not occur in this log"

@@ -330,8 +330,8 @@ def test_server_binary_refuses_a_malformed_meta_config(tmp_path):
     behind; the first division by the batch size ends the process without a message).  Refused by name, exit code 1, before any device call --
     so this runs in the build container."""
     import subprocess
-    server = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "legion-1_amd", "csrc", "legion")
-    assert os.path.exists(server), "build the server: make -C legion-1_amd/csrc legion"
+    server = os.environ.get("LEGION_SERVER_BIN") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "legion-1_amd", "csrc", "legion")
+    assert os.path.exists(server), "build the server: make -C legion-1_amd/csrc legion"      # LEGION_SERVER_BIN: the sanitizer build of the binary
     cases = [("garbage", "fewer than eleven fields"), ("/d/ 8000 100 1000 16 10 10 10 0 1", "fewer than eleven fields"),
              ("/d/ 0 100 1000 16 10 10 10 0 1 0", "batch size < 1"), ("/d/ 8 0 1000 16 10 10 10 0 1 0", "node count < 1"),
              ("/d/ 8 100 -5 16 10 10 10 0 1 0", "negative edge count"), ("/d/ 8 100 1000 0 10 10 10 0 1 0", "feature dim < 1"),

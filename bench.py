@@ -320,45 +320,59 @@ def worker(args):
     c.head = head
     line = headline_line(c, head) if rank == 0 else {"legs_failed": [], "legs_skipped": [], "extra_legs": {}}
     c.guard = guard = LegGuard(c, line)
+    # Everything behind the headline is evidence beside it: whatever goes wrong in the glue between the legs (a leg's own failures are
+    # caught and reported by LegGuard), rank 0 still prints the line it has -- with the error named -- before the process ends non-zero.
+    try:
 
-    def budgeted(name, want, fn):
-        return run_budgeted(c, line, guard, name, want, fn)
+        def budgeted(name, want, fn):
+            return run_budgeted(c, line, guard, name, want, fn)
 
-    if world > 1 and args.cache == "replicated" and not args.no_unified_leg and args.table == "device":
-        line["unified_cache"] = budgeted("unified_cache", args.unified_timeout,
-                                         lambda: unified_summary(c, run_leg(c, unified=True, headline=False, min_time=args.extra_min_time)))
+        if world > 1 and args.cache == "replicated" and not args.no_unified_leg and args.table == "device":
+            line["unified_cache"] = budgeted("unified_cache", args.unified_timeout,
+                                             lambda: unified_summary(c, run_leg(c, unified=True, headline=False, min_time=args.extra_min_time)))
 
-    # measured streaming-copy rate of this box (float4 copy kernel sized like the gather, read + write bytes)
-    if rank == 0 and line.get("roofline") is not None:
-        line["roofline"]["measured_copy_GBps"] = measure_copy(c)
-        if (world == 1 and args.measure_traffic == "auto" and not args.headline_only and args.table == "device" and args.cache == "replicated"
-                and args.gather == "all" and args.pipeline == "serial" and c.budget.left() > 240.0):   # two passes of <= 90 s each
-            got = measure_traffic_in_run(args)
-            if got is not None:
-                line["roofline"].update(got)
-    if rank == 0 and world > 1 and args.cpu_baseline_seconds > 0 and c.budget.left() > 120.0:
-        # N > 1: the same baseline, short -- sampler + COO only (no 57 GB host copy of the table), <= 5 s of CPU time, on rank 0
-        # while the other ranks wait in the next collective
-        import copy
-        a1 = copy.copy(args)
-        a1.no_cpu_features, a1.cpu_baseline_seconds = True, min(5.0, args.cpu_baseline_seconds)
-        try:
-            line["cpu_baseline"] = run_cpu_baseline(a1, c.spec, c.indptr, c.indices, None, c.mine, c.my_labels, c.B, c.fan, c.steps_avail)
-        except Exception as ex:   # noqa: BLE001 -- reported baseline only
-            line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
-    if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0 and c.budget.left() > 150.0:   # reported baseline
-        feats = c.feats
-        if c.host_table is not None:   # the table already is host memory: view it, no copy
-            import ctypes
-            feats = np.ctypeslib.as_array(ctypes.cast(c.host_table, ctypes.POINTER(ctypes.c_float)), shape=(c.spec.V, c.spec.F))
-        try:
-            line["cpu_baseline"] = run_cpu_baseline(args, c.spec, c.indptr, c.indices, feats, c.mine, c.my_labels, c.B, c.fan, c.steps_avail)
-        except Exception as ex:   # noqa: BLE001 -- reported baseline only: never lose the headline line over it
-            line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
+        # measured streaming-copy rate of this box (float4 copy kernel sized like the gather, read + write bytes)
+        if rank == 0 and line.get("roofline") is not None:
+            try:
+                line["roofline"]["measured_copy_GBps"] = measure_copy(c)
+            except Exception as ex:   # noqa: BLE001 -- evidence beside the headline: never lose the line over it (e.g. no 8 GiB left at N > 1 behind the unified leg)
+                line["roofline"]["measured_copy_GBps"] = None
+                line["roofline"]["measured_copy_error"] = repr(ex)[:200]
+            if (world == 1 and args.measure_traffic == "auto" and not args.headline_only and args.table == "device" and args.cache == "replicated"
+                    and args.gather == "all" and args.pipeline == "serial" and c.budget.left() > 240.0):   # two passes of <= 90 s each
+                got = measure_traffic_in_run(args)
+                if got is not None:
+                    line["roofline"].update(got)
+        if rank == 0 and world > 1 and args.cpu_baseline_seconds > 0 and c.budget.left() > 120.0:
+            # N > 1: the same baseline, short -- sampler + COO only (no 57 GB host copy of the table), <= 5 s of CPU time, on rank 0
+            # while the other ranks wait in the next collective
+            import copy
+            a1 = copy.copy(args)
+            a1.no_cpu_features, a1.cpu_baseline_seconds = True, min(5.0, args.cpu_baseline_seconds)
+            try:
+                line["cpu_baseline"] = run_cpu_baseline(a1, c.spec, c.indptr, c.indices, None, c.mine, c.my_labels, c.B, c.fan, c.steps_avail)
+            except Exception as ex:   # noqa: BLE001 -- reported baseline only
+                line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
+        if rank == 0 and world == 1 and args.cpu_baseline_seconds > 0 and c.budget.left() > 150.0:   # reported baseline
+            feats = c.feats
+            if c.host_table is not None:   # the table already is host memory: view it, no copy
+                import ctypes
+                feats = np.ctypeslib.as_array(ctypes.cast(c.host_table, ctypes.POINTER(ctypes.c_float)), shape=(c.spec.V, c.spec.F))
+            try:
+                line["cpu_baseline"] = run_cpu_baseline(args, c.spec, c.indptr, c.indices, feats, c.mine, c.my_labels, c.B, c.fan, c.steps_avail)
+            except Exception as ex:   # noqa: BLE001 -- reported baseline only: never lose the headline line over it
+                line["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
 
-    for name in extra_leg_names(c):      # BASELINE configs 4 and 5, same processes, same line (after everything that needs the headline graph)
-        line["extra_legs"][name] = budgeted(name, args.extra_timeout, lambda name=name: extra_leg(c, name))
+        for name in extra_leg_names(c):      # BASELINE configs 4 and 5, same processes, same line (after everything that needs the headline graph)
+            line["extra_legs"][name] = budgeted(name, args.extra_timeout, lambda name=name: extra_leg(c, name))
 
+    except Exception as ex:   # noqa: BLE001
+        if rank == 0:
+            import traceback
+            line["worker_error"] = {"error": repr(ex)[:300], "where": traceback.format_exc()[-1200:]}
+            line["time_budget"] = {"budget_s": args.time_budget, "used_s": round(time.time() - c.budget.t0, 1)}
+            emit_line(line)
+        raise
     if rank == 0:
         line["time_budget"] = {"budget_s": args.time_budget, "used_s": round(time.time() - c.budget.t0, 1)}
         emit_line(line)

@@ -331,3 +331,20 @@ def test_a_hung_leg_and_the_budget_the_line_is_printed_in_time():
     assert r.returncode == 0, r.stderr[-1500:]
     line = json.loads(r.stdout.splitlines()[-1])
     assert line["extra_legs"]["lp"] == {"skipped": "time budget"} and line["legs_skipped"][0]["leg"] == "lp" and line["legs_failed"] == []
+
+
+def test_served_schedule_windows_stay_inside_the_training_part_of_an_epoch():
+    """The served leg's timing windows (bench.served_schedule_windows): K consecutive TRAINING batches of one epoch, the first `warm` of every
+    epoch left out, never a validation / test batch inside, measured arrival to arrival."""
+    ts, vs, epochs, K, warm = 24, 1, 3, 9, 5
+    total = (ts + vs) * epochs + 1
+    t = [0.001 * i for i in range(total)]
+    t[ts] += 0.5                                   # the validation batch of epoch 0 arrives late: no window may see it
+    wins = bench.served_schedule_windows(t, ts, vs, epochs, K, warm)
+    per = ts + vs
+    assert [w[1] for w in wins] == [e * per + warm + k * K for e in range(epochs) for k in range((ts - warm) // K)]
+    for secs, first in wins:
+        e = first // per
+        assert first - e * per >= warm and first + K <= e * per + ts          # inside the training part, behind the warm-up
+        assert abs(secs - K * 0.001) < 1e-9                                    # K inter-arrival gaps; the late validation batch is outside
+    assert bench.served_schedule_windows(t, ts, vs, epochs, 30, warm) == []    # a window longer than an epoch's training part: none

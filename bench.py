@@ -778,7 +778,12 @@ def served_leg(c, workload, fan, ref_leg):
             "edges_per_batch": round(e_mean, 1), "unique_nodes_per_batch": round(n_mean, 1),
             "served_batches_equal_the_timed_ones": same,
             "ms_per_step_same_schedule_in_process": lv, "ratio_to_alt_schedule_levels": round(ms / lv, 4) if lv else None,
-            "ms_per_step_overlap_in_process": ov, "ms_per_step_serial_in_process": round(ref_ms, 4),
+            "ms_per_step_overlap_in_process": ov, "ratio_to_alt_schedule": round(ms / ov, 4) if ov else None,
+            "ms_per_step_serial_in_process": round(ref_ms, 4),
+            # which gather formulation the server's runner chose after its pre-sampling epoch (LEGION_RUNNER_GATHER=auto): "per level" is the
+            # schedule of alt_schedule_levels, "one launch over all rows" that of alt_schedule (overlap)
+            "server_gather": next((ln.split("Runner gather:")[1].strip() for ln in log_text.splitlines() if "Runner gather:" in ln),
+                                  os.environ.get("LEGION_RUNNER_GATHER")),
             # (sampler + gather algorithmic bytes of the K timed batches, per batch) / served time per batch / 8 TB/s
             "pipeline_frac": round(float(ref_leg["job_bytes"]) / args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "server_ready_s": round(ready_s, 2), "server_tables": "generated in HBM" if "Tables generated in HBM" in log_text else "?",

@@ -1,3 +1,7 @@
+# HISTORICAL RECORD (rounds 3 / 4): this script rebuilds or REPLACES legion-1_amd/csrc/liblegion_amd.so in place -- a killed run leaves an invalid
+# library behind.  Since round 5 a variant library is built with `make -C legion-1_amd/csrc variant VARIANT=... VARIANT_FLAGS=...` and selected through
+# $LEGION_LIB (profiles/ab_kernels.sh, profiles/r05_runs_robust.sh); the shipped library is never touched.  Kept as the record of what was run.
+[ "${LEGION_RUN_HISTORICAL:-0}" = 1 ] || { echo "$0: historical script that overwrites the shipped library; see its header (LEGION_RUN_HISTORICAL=1 to run it anyway)"; exit 1; }
 # round 4, call e: robustness of the final build -- determinism soak at two shapes, randomised differential stress (incl. the fused lookups),
 # parity + full-shape suites with the sampler tile built as 256 and 2048 (the full-shape oracle comparison included)
 O=gpurun_out/r04k

@@ -1,3 +1,7 @@
+# HISTORICAL RECORD (rounds 3 / 4): this script rebuilds or REPLACES legion-1_amd/csrc/liblegion_amd.so in place -- a killed run leaves an invalid
+# library behind.  Since round 5 a variant library is built with `make -C legion-1_amd/csrc variant VARIANT=... VARIANT_FLAGS=...` and selected through
+# $LEGION_LIB (profiles/ab_kernels.sh, profiles/r05_runs_robust.sh); the shipped library is never touched.  Kept as the record of what was run.
+[ "${LEGION_RUN_HISTORICAL:-0}" = 1 ] || { echo "$0: historical script that overwrites the shipped library; see its header (LEGION_RUN_HISTORICAL=1 to run it anyway)"; exit 1; }
 # round 4, call g: the host mirror of the counters in the hand-off slab -- IPC end-to-end tests, then the server loop as a trainer sees it with
 # the mirror (new) and with the library of the commit before ("old": trainer reads the counters with a blocking device copy), alternating
 O=$GRAFT_REPO_ROOT/gpurun_out/r04p

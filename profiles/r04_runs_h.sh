@@ -1,3 +1,7 @@
+# HISTORICAL RECORD (rounds 3 / 4): this script rebuilds or REPLACES legion-1_amd/csrc/liblegion_amd.so in place -- a killed run leaves an invalid
+# library behind.  Since round 5 a variant library is built with `make -C legion-1_amd/csrc variant VARIANT=... VARIANT_FLAGS=...` and selected through
+# $LEGION_LIB (profiles/ab_kernels.sh, profiles/r05_runs_robust.sh); the shipped library is never touched.  Kept as the record of what was run.
+[ "${LEGION_RUN_HISTORICAL:-0}" = 1 ] || { echo "$0: historical script that overwrites the shipped library; see its header (LEGION_RUN_HISTORICAL=1 to run it anyway)"; exit 1; }
 # round 4, call h: SAFE timing probe of k_write's tile-count prefix: a variant library builds the prefix 1 / 2 / 3 times per workgroup (same result,
 # bit-exact output -- checked first); the difference between the rows is what one prefix build costs
 O=$GRAFT_REPO_ROOT/gpurun_out/r04v

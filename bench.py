@@ -598,7 +598,13 @@ def extra_leg(c, name):
         c2.B = a.batch
         make_seeds(c2)
         leg = run_leg(c2, unified=False, headline=False, min_time=a.min_time)
-        return leg_summary(c2, leg, "link-prediction seed batches [src | pos | neg] (lp_sage.py:87-90) on the headline graph, replicated tables")
+        out = leg_summary(c2, leg, "link-prediction seed batches [src | pos | neg] (lp_sage.py:87-90) on the headline graph, replicated tables")
+        if c.world == 1 and c.budget.left() > 90.0:
+            try:      # config 5 as a trainer sees it: the server generates the same seed lists (synth: source + meta flag 2)
+                out["served"] = served_leg(c2, c.args.workload, c2.fan, leg, lp=True)
+            except Exception as ex:   # noqa: BLE001 -- the leg's own numbers stay valid
+                out["served"] = {"error": repr(ex)[:300]}
+        return out
     if name == "cached_gather":
         if not c.spec.name.startswith(c.args.workload):     # an earlier leg replaced the headline graph
             adopt_graph(c.args.workload)
@@ -684,7 +690,7 @@ def served_schedule_windows(t, train_step, valid_step, epochs, K_steps, warm):
     return out
 
 
-def served_leg(c, workload, fan, ref_leg):
+def served_leg(c, workload, fan, ref_leg, lp=False):
     """The whole path through the reference's surface, as a trainer sees it: the `legion` server binary -- started as a
     FRESH child process, dataset source `synth:<workload>` (the tables generated in its own HBM by the legion_synth_* calls this file uses),
     pre-sampling epoch, then its default software-pipelined RunOnce loop (runner.cpp; Server.cu:301-328) -- hands every batch of its schedule
@@ -700,7 +706,12 @@ def served_leg(c, workload, fan, ref_leg):
     server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
     if not os.path.exists(server):
         raise RuntimeError("the server binary is missing: make -C legion-1_amd/csrc legion")
-    train_step = (spec.n_train - 1) // B
+    n_seeds = spec.n_train
+    if lp:      # meta flag 2 on a synth: source: the server generates the [src | pos | neg] seed list itself (one triple per training id)
+        if B % 3:
+            raise RuntimeError("link-prediction batches need a batch size divisible by 3")
+        n_seeds = -(-spec.n_train // (B // 3)) * B
+    train_step = (n_seeds - 1) // B
     # windows of K consecutive training batches inside one epoch: a shape with few batches per epoch (products: 24) gets shorter windows
     warm = min(args.warmup, train_step // 4)
     K_win = min(args.steps, train_step - warm - 1)
@@ -713,7 +724,7 @@ def served_leg(c, workload, fan, ref_leg):
     src = "synth:%s" % workload + ("" if (args.scale == 1.0 and args.skew == 205) else ":%r" % args.scale) + ("" if args.skew == 205 else ":%d" % args.skew)
     meta = os.path.join(tmp, "meta_config")
     with open(meta, "w") as f:
-        f.write("%s %d %d 0 %d %d %d %d 0 %d 0" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, epochs))
+        f.write("%s %d %d 0 %d %d %d %d 0 %d %d" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, epochs, 2 if lp else 0))
     env = dict(os.environ, LEGION_IPC_NAMESPACE="bs%d_%d_" % (os.getpid(), len(c.children)), HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("LEGION_LOG", None)          # the server's log is its stdout (a file here), as with the reference
     if c.local_rank != 0:
@@ -771,7 +782,7 @@ def served_leg(c, workload, fan, ref_leg):
             "value": round(e_mean / (ms * 1e-3), 1), "unit": "edges/s", "ms_per_step": round(ms, 4),
             "feature_GBps": round(n_mean * 4 * spec.F / (ms * 1e-3) / 1e9, 2), "batch": B, "fanout": list(fan), "V": spec.V, "F": spec.F,
             "schedule": {"train_steps": ts, "valid_steps": vs, "test_steps": es, "epochs": epochs, "batches_served": len(t),
-                         "eval_batch_seeds": n_eval},
+                         "eval_batch_seeds": n_eval, "seeds": "link-prediction [src | pos | neg] lists generated by the server (meta flag 2)" if lp else "training ids"},
             "windows": len(wins), "steps_per_window": K_win,
             "window_ms_min_median_max": [round(float(secs.min()) * 1e3, 4), round(med * 1e3, 4), round(float(secs.max()) * 1e3, 4)],
             "all_training_batches_ms_per_step": round(train_t / (ts * epochs) * 1e3, 4),

@@ -562,7 +562,10 @@ void Server_Initialize(Server* s, int global_shard_count)
         for (int32_t i = 0; i < m.training_set_num; i++) training_ids[i] = legion_synth_seed_id_host(i, V, spec.M2, spec.C2);
         for (int32_t i = 0; i < m.validation_set_num; i++) validation_ids[i] = legion_synth_seed_id_host((int64_t)spec.n_train + i, V, spec.M2, spec.C2);
         for (int32_t i = 0; i < m.testing_set_num; i++) testing_ids[i] = legion_synth_seed_id_host((int64_t)spec.n_train + spec.n_valid + i, V, spec.M2, spec.C2);
-        if (m.partition == 2) { LEGION_ARG_ERROR("Server_Initialize: a synth: dataset has no pre-partitioned training lists (meta flag 2)"); return; }
+        if (m.partition == 2 && m.raw_batch_size % 3 != 0) {
+            LEGION_ARG_ERROR("Server_Initialize: synth: link-prediction lists (meta flag 2) need a batch size divisible by 3 ([src | pos | neg] thirds, lp_sage.py:87-90)");
+            return;
+        }
     } else {
     // Load_Graph / Load_Feature (GPUGraphStore.cu:254-325): pinned, device-mapped host memory
     log_out() << "Start load graph\n";
@@ -588,7 +591,32 @@ void Server_Initialize(Server* s, int global_shard_count)
     // seed split, GPUGraphStore.cu:332-414
     s->tr_ids.assign(G, {}); s->va_ids.assign(G, {}); s->te_ids.assign(G, {});
     s->tr_lab.assign(G, {}); s->va_lab.assign(G, {}); s->te_lab.assign(G, {});
-    if (m.partition == 2) {
+    if (m.partition == 2 && synth) {
+        // synth: source + flag 2: the per-GPU link-prediction lists are GENERATED (legion_synth_lp_seeds, the rule of synth.lp_trainingset): one
+        // triple per training id in list order, dealt by src % G with its GLOBAL number, every batch laid out as [src | pos | neg] thirds.
+        DeviceGuard guard(0);
+        for (int g = 0; g < G; g++) {
+            std::vector<int32_t> srcs;
+            std::vector<int64_t> tno;
+            for (int64_t t = 0; t < (int64_t)training_ids.size(); t++)
+                if (training_ids[t] % G == g) { srcs.push_back(training_ids[t]); tno.push_back(t); }
+            const int64_t n = (int64_t)srcs.size(), k = m.raw_batch_size / 3;
+            const int64_t n_out = (n + k - 1) / k * m.raw_batch_size;
+            s->tr_ids[g].assign((size_t)n_out, 0);
+            if (n == 0) continue;
+            int32_t *d_src = nullptr, *d_out = nullptr;
+            int64_t* d_tno = nullptr;
+            HIP_CHECK(hipMalloc(&d_src, (size_t)n * 4)); HIP_CHECK(hipMalloc(&d_tno, (size_t)n * 8)); HIP_CHECK(hipMalloc(&d_out, (size_t)n_out * 4));
+            if (!d_src || !d_tno || !d_out) return;
+            HIP_CHECK(hipMemcpy(d_src, srcs.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(d_tno, tno.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+            legion_synth_lp_seeds(nullptr, d_out, d_src, d_tno, n, m.raw_batch_size, s->indptr, s->indices, V, 1);
+            HIP_CHECK(hipMemcpy(s->tr_ids[g].data(), d_out, (size_t)n_out * 4, hipMemcpyDeviceToHost));
+            (void)hipFree(d_src); (void)hipFree(d_tno); (void)hipFree(d_out);
+        }
+        if (error_pending()) return;
+        log_out() << "Link-prediction seed lists generated: " << s->tr_ids[0].size() << " seeds on GPU 0\n";
+    } else if (m.partition == 2) {
         // Pre-partitioned training lists (extension, not in the reference): meta flag 2 = GPU g serves the file
         // trainingset_<G>_<g> verbatim.  Needed for link prediction on G > 1 GPUs: lp_sage.py:87-90 expects every
         // batch as [src | pos | neg] thirds, which neither split rule below preserves (synth.lp_trainingset writes them).

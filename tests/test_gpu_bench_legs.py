@@ -97,6 +97,8 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
         assert leg.get("error") is None and leg["value"] > 0 and leg["ms_per_step"] > 0, (name, leg)
         assert 0 < leg["gather_frac_of_hbm_peak"] < 1 and leg["sampler_us_per_batch"] > 0 and 0 < leg["pipeline_frac"] < 1, (name, leg)
     assert legs["lp"]["batch"] % 3 == 0 and legs["lp"]["F"] == 128
+    lps = legs["lp"]["served"]        # config 5 through the server: it generates the [src | pos | neg] lists itself (synth: source + meta flag 2)
+    assert lps.get("error") is None and lps["served_batches_equal_the_timed_ones"] is True and lps["value"] > 0 and "link-prediction" in lps["schedule"]["seeds"], lps
     cg = legs["cached_gather"]
     assert cg["Kg"] == 1 and 0.2 < cg["cached_fraction_of_V"] < 0.3 and cg["F"] == 128
     assert min(cg["rows_last_batch"][k] for k in ("own_shard", "backing_table")) > 0 and cg["rows_last_batch"]["peer_shards"] == 0

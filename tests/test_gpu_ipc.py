@@ -147,6 +147,65 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
             assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"])
 
 
+@pytest.mark.parametrize("G", [1, 2])
+def test_server_synth_link_prediction_lists(tmp_path, synth, oracle, G):
+    """`synth:` source + meta flag 2: the per-GPU link-prediction seed lists are generated by the server (legion_synth_lp_seeds: one triple per
+    training id, dealt by src % G with its global number, batches laid out as [src | pos | neg] thirds, lp_sage.py:87-90) -- what bench.py's `lp` leg
+    serves at the papers100M shape.  Every served batch against the oracle run on synth.lp_trainingset (the numpy statement of the rule): the thirds
+    survive, duplicate seeds keep the last-occurrence position rule."""
+    spec = synth.spec_for("products", scale=0.004)
+    ds = synth.generate(spec)
+    B, fan, epochs = 510, [10, 5], 1
+    meta = str(tmp_path / "meta_config")
+    with open(meta, "w") as f:
+        f.write("synth:products:0.004 %d %d %d %d %d 100 60 0 %d 2" % (B, spec.V, ds.E, spec.F, spec.n_train, epochs))
+    env = dict(os.environ, LEGION_IPC_NAMESPACE="lp%d_%d_" % (os.getpid(), G), HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_CLIENT_DUMP_SEEDS="1")
+    log = str(tmp_path / "server.log")
+    with open(log, "w") as lf:
+        server = subprocess.Popen([SERVER, str(G), "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=str(tmp_path))
+    clients = []
+    try:
+        _wait_ready(server, log)
+        for g in range(G):
+            out = str(tmp_path / ("client%d.json" % g))
+            clients.append((out, subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_client.py"), str(spec.F), str(epochs), out],
+                                                  env=dict(env, LEGION_IPC_DEVICE=str(g)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        for out, c in clients:
+            stdout, _ = c.communicate(timeout=300)
+            assert c.returncode == 0, stdout[-3000:]
+        server.wait(timeout=60)
+        assert server.returncode == 0, open(log).read()[-3000:]
+    finally:
+        for _, c in clients:
+            if c.poll() is None:
+                c.kill()
+        if server.poll() is None:
+            server.kill()
+    assert "Link-prediction seed lists generated" in open(log).read()
+    lists = [synth.lp_trainingset(ds, len(ds.train), B, rank=g, world=G) for g in range(G)]
+    va, te = oracle.split_seeds(ds.valid[:100], G), oracle.split_seeds(ds.test[:60], G)
+    steps, tb, vb, sb = oracle.coordinate([len(x) for x in lists], [len(p) for p in va], [len(p) for p in te], B)
+    orc = oracle.OracleRunner(ds.indptr, ds.indices, ds.features, spec.V, spec.F, B, fan)
+    k, dup = B // 3, 0
+    for g in range(G):
+        got = json.load(open(clients[g][0]))
+        assert got["steps"] == steps.tolist() and len(got["batches"]) == oracle.max_step(steps, epochs)
+        sets = {0: lists[g], 1: va[g], 2: te[g]}
+        bs = {0: int(tb[g]), 1: int(vb[g]), 2: int(sb[g])}
+        for rec in got["batches"]:
+            mode, local = oracle.schedule(steps, epochs, rec["b"])
+            ids = sets[mode]
+            ref = orc.run_batch(ids, ds.labels[ids], local, mode=mode, batch_size=bs[mode])
+            assert rec["ids"] == sha(ref["ids"]) and rec["features"] == sha(ref["features"]) and rec["labels"] == sha(ref["labels"]), (g, rec["b"])
+            assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"]), (g, rec["b"])
+            if mode == 0:       # the thirds: sources of this GPU, a neighbour (or the source itself) each, any node id
+                seeds = np.array(rec["seeds"])
+                assert len(seeds) == B and np.array_equal(seeds, lists[g][local * B:(local + 1) * B])
+                assert (seeds[:k] % G == g).all()
+                dup += int(len(np.unique(seeds)) < B)
+    assert dup > 0          # hot positives repeat inside a batch: the duplicate-seed path really ran
+
+
 def test_server_log_goes_to_stderr_on_request(tmp_path, synth):
     """$LEGION_LOG=stderr: every progress print of the library (the reference prints to stdout: "Train Steps", "Storage Initialized", "System is
     ready for serving" ...) goes to stderr, for a host that owns stdout (bench.py's one JSON line); unset: stdout, like the reference."""

@@ -641,10 +641,27 @@ def extra_leg(c, name):
     # HBM replica (a pinned-host backing table of 137 GB per process is not attempted here; tests/test_gpu_full_shape.py covers it)
     a.workload, a.fanout, a.task, a.topo_frac, a.cache_frac, a.no_exchange_leg = "uk-union", "25,10", "node", 0.3, 0.10, True
     c2.fan, c2.H = [25, 10], 2
+    served = None
+    if c.world == 1 and name == "partitioned_csr" and c.budget.left() > 120.0:
+        # config 4's SHAPE as a trainer sees it, before this process generates its own 160 GB copy (the two do not fit one GPU together): the server
+        # replicates the uk-union tables into its HBM -- on a 288 GB part nothing has to be partitioned or spilled -- and serves {25,10} batches
+        for k in ("indptr", "indices", "feats", "mine", "my_labels"):
+            setattr(c, k, None)
+            setattr(c2, k, None)
+        import torch
+        torch.cuda.empty_cache()
+        try:
+            served = served_leg(c2, "uk-union", c2.fan, None)
+            served["what"] = "REPLICATED configuration of the uk-union shape (the server holds the whole CSR + 137 GB of features in HBM; no fragments, no cache): " + served["what"]
+        except Exception as ex:   # noqa: BLE001
+            served = {"error": repr(ex)[:300]}
     adopt_graph("uk-union")
     leg = run_leg(c2, unified=True, headline=False, min_time=a.min_time)
-    return leg_summary(c2, leg, f"uk-union-shape graph, CSR sharded over the {c.world}-GPU clique (30 % of the adjacency rows in partitioned "
+    out_uk = leg_summary(c2, leg, f"uk-union-shape graph, CSR sharded over the {c.world}-GPU clique (30 % of the adjacency rows in partitioned "
                                 "fragments) + 10 % of the feature rows in the unified cache, misses from the HBM replica")
+    if served is not None:
+        out_uk["served_replicated"] = served
+    return out_uk
 
 
 def served_consumer(argv):
@@ -717,7 +734,8 @@ def served_leg(c, workload, fan, ref_leg, lp=False):
     K_win = min(args.steps, train_step - warm - 1)
     if K_win < 4:
         raise RuntimeError("the shape has %d training batches per epoch; at least %d needed" % (train_step, warm + 5))
-    ref_ms = ref_leg["elapsed"] / args.steps * 1e3
+    ref_leg = ref_leg or {}          # None: no in-process leg of this configuration to compare with (uk-union replicated: its tables and the server's do not fit together)
+    ref_ms = ref_leg["elapsed"] / args.steps * 1e3 if ref_leg else 0.6
     epochs = args.served_epochs or int(max(2, min(50, -(-2000.0 // (train_step * ref_ms)))))
     n_eval = min(512, spec.n_valid, spec.n_test)         # one validation / test batch per epoch: the schedule stays training batches
     tmp = tempfile.mkdtemp(prefix="legion_served_")
@@ -790,13 +808,15 @@ def served_leg(c, workload, fan, ref_leg, lp=False):
             "served_batches_equal_the_timed_ones": same,
             "ms_per_step_same_schedule_in_process": lv, "ratio_to_alt_schedule_levels": round(ms / lv, 4) if lv else None,
             "ms_per_step_overlap_in_process": ov, "ratio_to_alt_schedule": round(ms / ov, 4) if ov else None,
-            "ms_per_step_serial_in_process": round(ref_ms, 4),
+            "ms_per_step_serial_in_process": round(ref_ms, 4) if ref_leg else None,
             # which gather formulation the server's runner chose after its pre-sampling epoch (LEGION_RUNNER_GATHER=auto): "per level" is the
             # schedule of alt_schedule_levels, "one launch over all rows" that of alt_schedule (overlap)
             "server_gather": next((ln.split("Runner gather:")[1].strip() for ln in log_text.splitlines() if "Runner gather:" in ln),
                                   os.environ.get("LEGION_RUNNER_GATHER")),
             # (sampler + gather algorithmic bytes of the K timed batches, per batch) / served time per batch / 8 TB/s
-            "pipeline_frac": round(float(ref_leg["job_bytes"]) / args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            # served rows x (8F + 8) + the sampler's algorithmic bytes of the timed batches (in-process census; absent: gather bytes only)
+            "pipeline_frac": round(float(ref_leg["job_bytes"]) / args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ref_leg
+                             else round(n_mean * (8 * spec.F + 8) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "server_ready_s": round(ready_s, 2), "server_tables": "generated in HBM" if "Tables generated in HBM" in log_text else "?",
             "server_first_epoch_s": next((float(ln.split(":")[1].split()[0]) for ln in log_text.splitlines() if ln.startswith("First epoch cost")), None),
             "processes": "bench.py (idle) + legion + consumer"}

@@ -109,6 +109,8 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     assert "training batches per epoch" in p2["served"]["error"]          # 2 % of products has no full training batch: reported, not fatal
     pc = legs["partitioned_csr"]
     assert pc["F"] == 256 and pc["fanout"] == [25, 10] and pc["topo_rows_per_gpu"] > 0 and pc["Kg"] == 1
+    sr = pc["served_replicated"]     # config 4's shape through the server (replicated: the uk-union tables fit one GPU's HBM)
+    assert sr.get("error") is None and sr["value"] > 0 and sr["F"] == 256 and sr["served_batches_equal_the_timed_ones"] is None and sr["schedule"]["train_steps"] > 0
 
 
 def test_a_symmetric_exchange_failure_does_not_cost_the_rest_of_the_line():

@@ -251,7 +251,7 @@ class Budget:
         return got if got >= least else 0.0
 
 
-LEG_LEAST_S = {"unified_cache": 60.0, "served": 40.0}     # a leg that cannot get this much is skipped (default: 30 s)
+LEG_LEAST_S = {"unified_cache": 60.0, "served": 40.0, "served_all": 60.0}     # a leg that cannot get this much is skipped (default: 30 s)
 
 
 def run_budgeted(c, line, guard, name, want, fn):
@@ -308,6 +308,7 @@ def worker(args):
     c.K, c.D, c.S = K, D, S
     c.L = L = K.lib()
     c.fan = [int(x) for x in args.fanout.split(",")]
+    c.head_fan = list(c.fan)      # the headline's fan-out (later legs change c.fan on copies of the context)
     c.H = len(c.fan)
     c.B = args.batch
     if args.row_pitch == "dense":
@@ -545,7 +546,7 @@ class LegGuard:
 
 
 N1_LEGS = ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]   # run order: graph re-use first
-NN_LEGS = ["lp", "uk_union"]
+NN_LEGS = ["lp", "uk_union", "served_all"]     # served_all last: it starts other processes on every GPU of the job
 
 
 def extra_leg_names(c):
@@ -560,7 +561,7 @@ def extra_leg_names(c):
             return []
         return list(N1_LEGS) if c.world == 1 else list(NN_LEGS)
     names = [x for x in a.extra_legs.split(",") if x]
-    known = N1_LEGS + ["uk_union"]
+    known = N1_LEGS + ["uk_union", "served_all"]
     bad = [x for x in names if x not in known]
     if bad:
         raise SystemExit("bench.py: unknown --extra-legs %s" % bad)
@@ -592,6 +593,8 @@ def extra_leg(c, name):
 
     if name == "served":
         return served_leg(c, c.args.workload, c.fan, c.head)
+    if name == "served_all":
+        return served_all_leg(c) if c.rank == 0 else None
     if name == "lp":
         # lp_sage.py:87-90: [src | pos | neg] seed thirds; triples dealt to the ranks by src % N; the graph is the headline's
         a.task, a.batch = "lp", (c.B // 3) * 3
@@ -671,8 +674,11 @@ def served_consumer(argv):
     import ctypes as C
     import legion1_amd.capi as K
     hops, epochs = int(argv[0]), int(argv[1])
+    gpu = int(argv[2]) if len(argv) > 2 else 0        # logical GPU of the server this consumer is the trainer of (served_all: one per GPU)
     lib = K.lib()
-    lib.SetGPUDevice(0)
+    lib.SetGPUDevice(gpu)                             # physical device gpu % visible devices, as the server maps it
+    if len(argv) > 2:
+        os.environ["LEGION_IPC_DEVICE"] = str(gpu)    # row of the handle table (differs from the physical device on a shared GPU)
     c = C.c_void_p(lib.legion_ipc_client_open(-1))
     K.check()
     steps = (C.c_int32 * 3)()
@@ -688,7 +694,7 @@ def served_consumer(argv):
         nodes.append(nc[5 + 2 * hops])
         lib.legion_ipc_client_post(c)
     lib.legion_ipc_client_close(c)
-    sys.stdout.write(json.dumps({"steps": list(steps), "hops": hops, "t": [round(x - t[0], 7) for x in t],
+    sys.stdout.write(json.dumps({"steps": list(steps), "hops": hops, "t0": t[0], "t": [round(x - t[0], 7) for x in t],
                                  "edges": edges, "nodes": nodes}) + "\n")
 
 
@@ -820,6 +826,102 @@ def served_leg(c, workload, fan, ref_leg, lp=False):
             "server_ready_s": round(ready_s, 2), "server_tables": "generated in HBM" if "Tables generated in HBM" in log_text else "?",
             "server_first_epoch_s": next((float(ln.split(":")[1].split()[0]) for ln in log_text.splitlines() if ln.startswith("First epoch cost")), None),
             "processes": "bench.py (idle) + legion + consumer"}
+
+
+def served_all_leg(c):
+    """N > 1: the reference's own deployment on the N GPUs of the node -- ONE `legion` server process driving all of them (a runner thread per GPU,
+    Server.cu:116-135; dataset source synth:<workload>, a replica of the tables generated in every GPU's HBM, seeds split tid % N) and N trainer-side
+    consumer processes, one per GPU (legion_ipc_client_*).  Started by rank 0 as fresh child processes while the bench's own ranks wait in the leg's
+    agreement collective; consumer-clock windows per GPU, the job's rate = sum of the GPUs' edges per batch / the slowest GPU's time per batch.
+    Never run on more than one physical GPU in any round (two logical GPUs on one device in tests/test_gpu_bench_legs.py): on a node this is a first run."""
+    import shutil
+    import tempfile
+    args, N = c.args, c.world
+    if c.shared_device and 2 * N + 1 > 6:
+        return {"skipped": "a shared-device rehearsal may hold at most 6 GPU processes; this leg needs %d (N ranks + server + N consumers)" % (2 * N + 1)}
+    workload = args.workload
+    spec, fan, H, B = c.S.spec_for(workload, scale=args.scale), c.head_fan, len(c.head_fan), args.batch
+    server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
+    per_gpu = spec.n_train // N
+    train_step = (per_gpu - 1) // B - 1          # lower bound (the split is by tid % N: shards differ by a few ids)
+    warm = min(args.warmup, max(train_step, 0) // 4)
+    K_win = min(args.steps, train_step - warm - 1)
+    if K_win < 4:
+        raise RuntimeError("the shape has about %d training batches per GPU and epoch; more needed" % train_step)
+    epochs = args.served_epochs or int(max(2, min(50, -(-2000.0 // (train_step * 0.5)))))
+    n_eval = min(512 * N, spec.n_valid, spec.n_test)
+    tmp = tempfile.mkdtemp(prefix="legion_served_all_")
+    src = "synth:%s" % workload + ("" if (args.scale == 1.0 and args.skew == 205) else ":%r" % args.scale) + ("" if args.skew == 205 else ":%d" % args.skew)
+    meta = os.path.join(tmp, "meta_config")
+    with open(meta, "w") as f:
+        f.write("%s %d %d 0 %d %d %d %d 0 %d 0" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, epochs))
+    env = dict(os.environ, LEGION_IPC_NAMESPACE="ba%d_%d_" % (os.getpid(), len(c.children)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("LEGION_LOG", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LEGION_IPC_DEVICE"):
+        env.pop(k, None)
+    log_path = os.path.join(tmp, "server.log")
+    t0 = time.time()
+    srv, cons = None, []
+    try:
+        with open(log_path, "w") as lf:
+            srv = subprocess.Popen([server, str(N), "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=tmp)
+        c.children.append(srv)
+        while "System is ready for serving" not in open(log_path, errors="ignore").read():
+            if srv.poll() is not None:
+                raise RuntimeError("the server exited before serving: " + open(log_path, errors="ignore").read()[-600:])
+            time.sleep(0.05)
+        ready_s = time.time() - t0
+        for g in range(N):
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--served-consumer", str(H), str(epochs), str(g)], env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            cons.append(p)
+            c.children.append(p)
+        outs = []
+        for g, p in enumerate(cons):
+            out, err = p.communicate()
+            if p.returncode != 0:
+                raise RuntimeError("consumer %d failed (%d): %s" % (g, p.returncode, (out + err)[-500:]))
+            outs.append(json.loads(out.strip().splitlines()[-1]))
+        srv.wait(timeout=60)
+        if srv.returncode != 0:
+            raise RuntimeError("the server failed (%d): %s" % (srv.returncode, open(log_path, errors="ignore").read()[-600:]))
+        log_text = open(log_path, errors="ignore").read()
+    finally:
+        for p in cons + [srv]:
+            if p is not None and p.poll() is None:
+                p.kill()
+                p.wait()
+        shutil.rmtree(tmp, ignore_errors=True)
+    ts, vs, es = outs[0]["steps"]
+    per_gpu_ms, per_gpu_edges, per_gpu_nodes, n_windows = [], [], [], []
+    for got in outs:
+        if got["steps"] != [ts, vs, es] or len(got["t"]) != (ts + vs) * epochs + es:
+            raise RuntimeError("the consumers disagree about the schedule: %s vs %s" % (got["steps"], [ts, vs, es]))
+        wins = served_schedule_windows(got["t"], ts, vs, epochs, min(K_win, ts - warm - 1), warm)
+        is_train = np.array([(b % (ts + vs)) < ts for b in range((ts + vs) * epochs)] + [False] * es)
+        per_gpu_ms.append(float(np.median([w[0] for w in wins])) / min(K_win, ts - warm - 1) * 1e3)
+        per_gpu_edges.append(float(np.asarray(got["edges"], np.int64)[is_train].mean()))
+        per_gpu_nodes.append(float(np.asarray(got["nodes"], np.int64)[is_train].mean()))
+        n_windows.append(len(wins))
+    slow = max(per_gpu_ms)
+    same = None
+    if c.head.get("edges_per_step") is not None:      # rank 0's own census of its shard's batches W .. W + K - 1 against what GPU 0's trainer received
+        idx = (args.warmup + np.arange(args.steps)) % ts
+        same = bool(np.array_equal(np.asarray(outs[0]["edges"], np.int64)[idx], c.head["edges_per_step"]))
+    span = [o["t0"] for o in outs]
+    return {"what": "ONE `legion` server process over the %d GPUs (a runner thread and a replica of the %s tables per GPU, seeds split tid %% %d) + %d consumer "
+                    "processes on legion_ipc_client_* -- the reference's deployment (Server.cu:116-135, legion_graphsage.py:186-190); consumer-clock windows per GPU; "
+                    "value = sum of the GPUs' edges per batch / the slowest GPU's time per batch" % (N, src, N, N)
+                    + ("; REHEARSAL: every logical GPU sits on ONE physical device" if c.shared_device else ""),
+            "value": round(sum(per_gpu_edges) / (slow * 1e-3), 1), "unit": "edges/s", "ms_per_step": round(slow, 4), "n_gpus": N,
+            "ms_per_step_per_gpu": [round(x, 4) for x in per_gpu_ms], "edges_per_batch_per_gpu": [round(x, 1) for x in per_gpu_edges],
+            "feature_GBps": round(sum(per_gpu_nodes) * 4 * spec.F / (slow * 1e-3) / 1e9, 2),
+            "schedule": {"train_steps": ts, "valid_steps": vs, "test_steps": es, "epochs": epochs, "batches_served_per_gpu": len(outs[0]["t"])},
+            "windows_per_gpu": n_windows, "steps_per_window": min(K_win, ts - warm - 1),
+            "first_batch_spread_ms": round((max(span) - min(span)) * 1e3, 3),
+            "gpu0_batches_equal_rank0s_timed_ones": same,
+            "server_ready_s": round(ready_s, 2),
+            "server_gather": [ln.split("Runner gather:")[1].strip()[:60] for ln in log_text.splitlines() if "Runner gather:" in ln][:N],
+            "shared_device": bool(c.shared_device), "processes": "%d bench ranks (idle) + legion + %d consumers" % (N, N)}
 
 
 def leg_summary(c, leg, what):

@@ -228,7 +228,7 @@ def test_extra_leg_plan():
         c.world, c.args = world, bench.parse(list(flags))
         return bench.extra_leg_names(c)
     assert names(1) == ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]     # legs that re-use the headline graph first
-    assert names(8) == ["lp", "uk_union"] and names(2) == ["lp", "uk_union"]                              # the multi-GPU command is frozen (r03 keys)
+    assert names(8) == ["lp", "uk_union", "served_all"] and names(2) == ["lp", "uk_union", "served_all"]    # r03 keys + (round 5, last) the one-server-process deployment
     assert names(1, "--extra-legs", "none") == [] and names(8, "--extra-legs", "none") == []
     assert names(1, "--workload", "products") == [] and names(1, "--task", "lp") == [] and names(1, "--headline-only") == []   # auto: default workload only
     assert names(1, "--extra-legs", "products_3hop,lp") == ["lp", "products_3hop"]                      # explicit lists run in the canonical order

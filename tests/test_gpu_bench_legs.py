@@ -45,6 +45,11 @@ def test_two_rank_line_has_every_leg():
     assert u["xgmi_read_GBps_per_gpu"] is None                       # two ranks on one device: not an xGMI number
     lp, uk = line["extra_legs"]["lp"], line["extra_legs"]["uk_union"]
     assert lp["value"] > 0 and lp["batch"] % 3 == 0 and uk["value"] > 0 and uk["Kg"] == 2 and uk["topo_rows_per_gpu"] > 0 and uk["F"] == 256
+    # the reference's deployment: ONE server process over both (logical) GPUs + one consumer process per GPU, started by rank 0 (last leg)
+    sa = line["extra_legs"]["served_all"]
+    assert list(line["extra_legs"]) == ["lp", "uk_union", "served_all"]
+    assert sa.get("error") is None and sa["n_gpus"] == 2 and sa["value"] > 0 and len(sa["ms_per_step_per_gpu"]) == 2 and sa["shared_device"] is True, sa
+    assert sa["gpu0_batches_equal_rank0s_timed_ones"] is True and "REHEARSAL" in sa["what"] and len(sa["server_gather"]) == 2
 
 
 def test_a_failed_leg_is_named_and_the_other_legs_survive():

@@ -140,7 +140,7 @@ def free_port():
 def launch_children(args, argv, popen=subprocess.Popen, poll_s=0.2, grace_s=20.0, script=None):
     port = free_port()
     environ = dict(os.environ)
-    environ.setdefault("LEGION_BENCH_T0", repr(time.time()))       # the time budget counts from here
+    environ["LEGION_BENCH_T0"] = repr(time.time())                 # the time budget counts from here (never a stale value of an outer shell)
     # stdout carries exactly ONE JSON line (rank 0's): every other rank writes to the parent's stderr, whatever it prints
     procs = [popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=child_env(environ, r, args.gpus, port),
                    stdout=None if r == 0 else sys.stderr)

@@ -276,7 +276,8 @@ def worker(args):
     claim_stdout()
     c = Ctx()
     c.args = args
-    c.budget = Budget(args.time_budget, os.environ.get("LEGION_BENCH_T0"))
+    # the budget counts from the start of the self-launching parent (only its own children believe LEGION_BENCH_T0), else from here
+    c.budget = Budget(args.time_budget, os.environ.get("LEGION_BENCH_T0") if os.environ.get("LEGION_BENCH_SPAWNED") == "1" else None)
     c.children = []       # child processes a leg started (the `served` leg's server and consumer): the watchdog stops them
     c.rank = rank = int(os.environ.get("RANK", "0"))
     c.world = world = int(os.environ.get("WORLD_SIZE", "1"))

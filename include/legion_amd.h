@@ -468,6 +468,9 @@ typedef struct RunnerParams {
     int global_batch_id;
     int in_memory;
 } RunnerParams;
+/* The decision rule of $LEGION_RUNNER_GATHER=auto as a pure function (host only): 1 = ONE gather over all rows behind the last hop, 0 = one per level
+ * (the reference's op list).  rows: unique nodes of a batch; slots: sum over the hops of (input nodes x fan-out).  profiles/r05_runner_gather.md */
+int legion_runner_gather_estimate(int32_t F, double rows, double slots, double* gather_us, double* sampler_us);
 Runner* NewGPURunner(void);
 void Runner_Initialize(Runner* r, RunnerParams* params);
 void Runner_InitializeFeaturesBuffer(Runner* r, RunnerParams* params);

@@ -227,6 +227,7 @@ _SIGS = {
     "legion_ipc_client_post": (None, [vp]), "legion_ipc_client_post_nosync": (None, [vp]), "legion_ipc_client_buffer": (vp, [vp, i32]),
     "legion_ipc_client_steps": (None, [vp, vp]), "legion_ipc_client_hops": (i32, [vp]), "legion_ipc_client_feature_rows": (i32, [vp]),
     "legion_ipc_client_read_counters": (None, [vp, vp, vp]), "legion_ipc_client_close": (None, [vp]),
+    "legion_runner_gather_estimate": (C.c_int, [i32, f64, f64, vp, vp]),
     "NewGPURunner": (vp, []), "Runner_Initialize": (None, [vp, vp]),
     "Runner_InitializeFeaturesBuffer": (None, [vp, vp]), "Runner_RunPreSc": (None, [vp, vp]),
     "Runner_RunOnce": (None, [vp, vp]), "Runner_Finalize": (None, [vp, vp]), "Runner_GetMemoryPool": (vp, [vp]),

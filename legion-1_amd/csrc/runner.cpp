@@ -52,6 +52,17 @@ struct Runner {
 
 extern "C" {
 
+// The estimate behind $LEGION_RUNNER_GATHER=auto (see Runner::gather_all): microseconds per batch of the gather (rows x (8F + 8) bytes at
+// 6 TB/s, 5.2 TB/s for rows that are not whole 128-byte lines) and of the sampler (45 ps per slot: the memory system's random-access rate).
+// Returns 1 when one gather over all rows behind the last hop is expected to win, 0 for the reference's per-level list.
+int legion_runner_gather_estimate(int32_t F, double rows, double slots, double* gather_us, double* sampler_us)
+{
+    const double g = rows * (8.0 * F + 8.0) / (((F * 4) % 128 == 0) ? 6.0e6 : 5.2e6), smp = slots * 45e-6;
+    if (gather_us) *gather_us = g;
+    if (sampler_us) *sampler_us = smp;
+    return g > smp ? 1 : 0;
+}
+
 Runner* NewGPURunner(void) { return new Runner(); }
 
 // GPURunner::Initialize, Server.cu:169-271
@@ -164,7 +175,8 @@ void Runner_InitializeFeaturesBuffer(Runner* r, RunnerParams* params)
             }
             const double rows = (double)GPUCache_MaxIdNum(cache, r->local_dev_id);
             const int F = r->float_attr_len;
-            const double gather_us = rows * (8.0 * F + 8.0) / (((F * 4) % 128 == 0) ? 6.0e6 : 5.2e6), sampler_us = slots * 45e-6;
+            double gather_us = 0.0, sampler_us = 0.0;
+            (void)legion_runner_gather_estimate(F, rows, slots, &gather_us, &sampler_us);
             r->gather_all = gather_us > sampler_us;
             log_out() << r->local_dev_id << " Runner gather: " << (r->gather_all ? "one launch over all rows behind the last hop" : "per level behind each hop")
                       << " (estimated gather " << (int)gather_us << " us, sampler " << (int)sampler_us << " us per batch)\n";

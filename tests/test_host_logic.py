@@ -348,3 +348,20 @@ def test_server_binary_refuses_a_malformed_meta_config(tmp_path):
     assert r.returncode == 1 and "meta_config missing" in r.stderr
     r = subprocess.run([server], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "usage:" in r.stderr
+
+
+def test_runner_gather_choice_at_the_baseline_shapes():
+    """$LEGION_RUNNER_GATHER=auto: the estimate the runner makes once after the pre-sampling epoch, at the measured batch statistics of the BASELINE
+    shapes (profiles/r05_runner_gather.md: `all` -2.8 % at papers100M {25,10,5}, -4 % at products {25,10}, +5.7 % at products {25,10,5})."""
+    import ctypes as C
+    import legion1_amd.capi as K
+    L = K.lib()
+    g, s_ = C.c_double(), C.c_double()
+    cases = [("papers100M {25,10,5}", 128, 1.94e6, 8000 * 25 + 0.196e6 * 10 + 0.9e6 * 5, 1),
+             ("products {25,10}", 100, 0.89e6, 8000 * 25 + 0.196e6 * 10, 1),
+             ("products {25,10,5}", 100, 2.13e6, 8000 * 25 + 0.196e6 * 10 + 1.96e6 * 5, 0),
+             ("uk-union {25,10}", 256, 1.24e6, 8000 * 25 + 0.2e6 * 10, 1)]
+    for name, F, rows, slots, want in cases:
+        assert L.legion_runner_gather_estimate(F, rows, slots, C.byref(g), C.byref(s_)) == want, (name, g.value, s_.value)
+        assert g.value > 0 and s_.value > 0
+    assert L.legion_runner_gather_estimate(128, 0.0, 0.0, None, None) == 0          # no pre-sampled batch: the reference's list

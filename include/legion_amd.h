@@ -414,7 +414,7 @@ int32_t* IPCEnv_GetAggSrc(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int32_t* IPCEnv_GetAggDst(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int32_t* IPCEnv_GetNodeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int32_t* IPCEnv_GetEdgeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
-/* extension: the slab carries a host mirror of both counter arrays of every (device, pipe) behind the reference's struct, so that a
+/* extension: a second shm object ("<name>_ext"; the shared slab itself stays the reference's 7180-byte struct) carries a host mirror of both counter arrays of every (device, pipe), so that a
  * trainer reads them without a device copy (the reference's blocking cudaMemcpy, ipc_cuda_kernel.cu:195-196, synchronises the trainer
  * with its own queued GPU work once per batch).  IPCEnv_MirrorCounters queues the copy of the current batch's counters on `stream`
  * (behind the kernels that wrote them; wait for that stream before posting); IPCEnv_IPCPost copies synchronously when it was not called;

@@ -6,7 +6,8 @@
 //   struct { int32 steps[3]; ipcMemHandle[8 dev][2 pipe][7 buf]; }   (12 + 8*2*7*64 = 7180 B;
 // hipIpcMemHandle_t is 64 bytes like cudaIpcMemHandle_t), named semaphores sem_r_D_P / sem_w_D_P
 // with initial value 0, producer: wait(sem_r) -> fill -> post(sem_w); consumer: wait(sem_w) ->
-// use -> post(sem_r).  Extension: one int32 (hop count) appended AFTER the reference struct.
+// use -> post(sem_r).  Extensions (hop count, counter mirror, feature-buffer rows) live in a SECOND shm
+// object "<name>_ext" (shmExt below): the shared slab itself is exactly the reference's 7180 bytes.
 #include "internal.h"
 
 #include <cerrno>
@@ -31,22 +32,28 @@ using namespace legion;
 
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle must be 64 bytes (CUDA_IPC_Service.cu:34-37)");
 
-struct shmStruct {
+struct shmStruct {           // the reference's slab, byte for byte (CUDA_IPC_Service.cu:34-37, ipc_cuda_kernel.cu:31-34): 7180 bytes, nothing appended
     int32_t steps[3];
     hipIpcMemHandle_t memHandle[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH][LEGION_MEMORY_USAGE];
-    int32_t ext_hops; // extension, outside the reference's 7180 bytes
-    // extension: host mirror of the two 16-int counter arrays of every (device, pipe), filled by the server before it posts the
-    // pipe.  The reference's trainer reads them with a blocking cudaMemcpy from the IPC device buffers (ipc_cuda_kernel.cu:195-196):
-    // on the legacy default stream that copy waits for everything the trainer has queued -- one implicit device synchronisation per
-    // batch.  A client that finds the magic set reads the mirror instead; the device buffers 5 / 6 stay valid for everybody else.
-    uint32_t ext_mirror_magic;
-    int32_t ext_counters[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH][32];   // nc[16] | ec[16]
-    // extension: rows the feature buffers of a device hold (InitializeFeaturesBuffer; 0 = not told).  The reference sizes them at 1.2 x the
-    // largest batch of the pre-sampling epoch (Server.cu:275) and its trainer views [nc9, F] of them unchecked (ipc_cuda_kernel.cu:200): a
-    // batch with more nodes reads past the allocation.  A client that knows the capacity refuses such a batch instead.
-    int32_t ext_feature_rows[LEGION_MAX_DEVICE];
 };
-static_assert(offsetof(shmStruct, ext_hops) == 12 + 8 * 2 * 7 * 64, "reference shm layout changed");
+static_assert(sizeof(shmStruct) == 12 + 8 * 2 * 7 * 64, "the reference's shm layout is 7180 bytes");
+// Everything this implementation adds lives in a SECOND shm object, "<name>_ext".  Rounds 1-4 appended it behind the reference struct in the
+// same object; but the reference's trainer opens the slab with sharedMemoryCreate (ipc_cuda_kernel.cu:45 -> helper_multiprocess.cpp:35), which
+// ftruncate()s it to ITS 7180 bytes -- cutting the appended words off under a running server (a SIGBUS on their next touch beyond the page).
+// With a separate object the shared one is exactly the reference's, whoever creates or truncates it (tests/test_ref_shm_compat.py drives the
+// reference's own helper against it).  A peer without the extension object simply does not find it: hops = 2, counters by device copy.
+struct shmExt {
+    uint32_t mirror_magic;    // kMirrorMagic: the server maintains the counter mirror below
+    int32_t hops;             // number of hops the server samples (0: not told -> 2, the reference's layout)
+    // rows the feature buffers of a device hold (InitializeFeaturesBuffer; 0 = not told).  The reference sizes them at 1.2 x the largest batch
+    // of the pre-sampling epoch (Server.cu:275) and its trainer views [nc9, F] of them unchecked (ipc_cuda_kernel.cu:200): a batch with more
+    // nodes reads past the allocation.  A client that knows the capacity refuses such a batch instead.
+    int32_t feature_rows[LEGION_MAX_DEVICE];
+    // host mirror of the two 16-int counter arrays of every (device, pipe), filled by the server before it posts the pipe.  The reference's
+    // trainer reads them with a blocking cudaMemcpy from the IPC device buffers (ipc_cuda_kernel.cu:195-196): on the legacy default stream that
+    // copy waits for everything the trainer has queued.  A client that finds the magic set reads the mirror instead; buffers 5 / 6 stay valid.
+    int32_t counters[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH][32];   // nc[16] | ec[16]
+};
 static const uint32_t kMirrorMagic = 0x4C474E43u;   // "LGNC"
 
 // $LEGION_IPC_NO_DEVICE=1 (test hook: build containers without a GPU, the host-sanitizer run of tests/test_ipc_env_cpu.py): the slab,
@@ -100,15 +107,16 @@ static const std::string& ipc_ns()
     return g_namespace;
 }
 static std::string shm_name() { return "/" + ipc_ns() + "simpleIPCshm"; }
+static std::string ext_name() { return shm_name() + "_ext"; }
 static std::string sem_name(const char* rw, int dev, int pipe)
 {
     return "/" + ipc_ns() + "sem_" + rw + "_" + std::to_string(dev) + "_" + std::to_string(pipe);
 }
 
 // sharedMemoryCreate (helper_multiprocess.cpp:5-47): shm_open(O_RDWR|O_CREAT) + ftruncate + mmap
-static void* shm_map(size_t sz, int* fd_out)
+static void* shm_map(size_t sz, int* fd_out, const std::string& name = shm_name(), bool create = true)
 {
-    int fd = shm_open(shm_name().c_str(), O_RDWR | O_CREAT, 0777);
+    int fd = shm_open(name.c_str(), create ? (O_RDWR | O_CREAT) : O_RDWR, 0777);
     if (fd < 0) return nullptr;
     struct stat st;
     if (fstat(fd, &st) == 0 && (size_t)st.st_size < sz && ftruncate(fd, (off_t)sz) != 0) { close(fd); return nullptr; }
@@ -290,6 +298,8 @@ static hipError_t vmm_import_fd(hipMemGenericAllocationHandle_t* h, int fd)
 struct IPCEnv {
     volatile shmStruct* shm = nullptr;
     int shm_fd = -1;
+    volatile shmExt* ext = nullptr;    // the extension object ("<name>_ext"); never null once NewIPCEnv succeeded
+    int ext_fd = -1;
     int32_t device_count = 0;
     std::vector<std::vector<void*>> ids, float_features, labels, agg_src, agg_dst, node_counter, edge_counter;
     std::vector<std::vector<sem_t*>> semr, semw;
@@ -326,10 +336,17 @@ IPCEnv* NewIPCEnv(int32_t device_count)
         LEGION_ARG_ERROR("NewIPCEnv: shm_open/mmap failed");
         return nullptr;
     }
+    e->ext = (volatile shmExt*)shm_map(sizeof(shmExt), &e->ext_fd, ext_name());
+    if (!e->ext) {
+        munmap((void*)e->shm, sizeof(shmStruct)); close(e->shm_fd);
+        delete e;
+        LEGION_ARG_ERROR("NewIPCEnv: shm_open/mmap of the extension object failed");
+        return nullptr;
+    }
     log_out() << "Shared Memory Opened\n";
     // $LEGION_IPC_ATTACH=1: another server process of this job already created the slab
     const char* attach = getenv("LEGION_IPC_ATTACH");
-    if (!(attach && attach[0] == '1')) memset((void*)e->shm, 0, sizeof(shmStruct));
+    if (!(attach && attach[0] == '1')) { memset((void*)e->shm, 0, sizeof(shmStruct)); memset((void*)e->ext, 0, sizeof(shmExt)); }
     e->device_count = device_count;
     auto rs = [&](std::vector<std::vector<void*>>& v) { v.assign(device_count, {}); };
     rs(e->ids); rs(e->float_features); rs(e->labels); rs(e->agg_src); rs(e->agg_dst); rs(e->node_counter); rs(e->edge_counter);
@@ -343,13 +360,13 @@ IPCEnv* NewIPCEnv(int32_t device_count)
 // synchronous).  Called with a device current; failure only costs the asynchronous path.
 static void pin_slab(IPCEnv* e)
 {
-    if (e->shm_pinned || !e->shm) return;
-    const size_t page = (size_t)sysconf(_SC_PAGESIZE), bytes = (sizeof(shmStruct) + page - 1) / page * page;
+    if (e->shm_pinned || !e->ext) return;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE), bytes = (sizeof(shmExt) + page - 1) / page * page;
     const char* no_pin = getenv("LEGION_IPC_NO_PIN");      // test hook: behave as if the runtime refused (the staging path below)
-    if (no_device()) { e->shm->ext_mirror_magic = kMirrorMagic; return; }
-    if (!(no_pin && no_pin[0] == '1') && hipHostRegister((void*)e->shm, bytes, hipHostRegisterPortable) == hipSuccess) e->shm_pinned = true;
+    if (no_device()) { e->ext->mirror_magic = kMirrorMagic; return; }
+    if (!(no_pin && no_pin[0] == '1') && hipHostRegister((void*)e->ext, bytes, hipHostRegisterPortable) == hipSuccess) e->shm_pinned = true;
     else (void)hipGetLastError();
-    e->shm->ext_mirror_magic = kMirrorMagic;    // the mirror is maintained either way (synchronously in IPCPost if need be)
+    e->ext->mirror_magic = kMirrorMagic;    // the mirror is maintained either way (synchronously in IPCPost if need be)
 }
 
 // Coordinate, CUDA_IPC_Service.cu:66-134
@@ -464,7 +481,7 @@ void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_
         if (!p) return;   // refused or out of memory: the error is sticky, nothing is registered
         e->float_features[device_id].push_back(p);
     }
-    e->shm->ext_feature_rows[device_id] = num_ids;
+    e->ext->feature_rows[device_id] = num_ids;
 }
 
 int32_t IPCEnv_GetRawBatchsize(IPCEnv* e) { return e->raw_batch_size; }
@@ -517,9 +534,9 @@ ENV_GETTER(EdgeCounter, edge_counter, int32_t)
 // pipe only after it has waited for that stream's work (the runner waits for an event recorded behind this call).
 void IPCEnv_MirrorCounters(IPCEnv* e, int32_t dev_id, int32_t current_pipe, void* stream)
 {
-    if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count || e->node_counter[dev_id].empty() || no_device()) return;
+    if (!e || !e->ext || dev_id < 0 || dev_id >= e->device_count || e->node_counter[dev_id].empty() || no_device()) return;
     const int q = current_pipe % e->pipeline_depth;
-    int32_t* m = (int32_t*)&e->shm->ext_counters[dev_id][q][0];
+    int32_t* m = (int32_t*)&e->ext->counters[dev_id][q][0];
     if (!e->shm_pinned) {           // the runtime refused to page-lock the slab: queue the copies into pinned staging words, IPCPost moves them
         if (!e->mirror_stage[dev_id][q] && hipHostMalloc((void**)&e->mirror_stage[dev_id][q], 32 * sizeof(int32_t), hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError();
@@ -536,26 +553,26 @@ int IPCEnv_SlabPinned(IPCEnv* e) { return e && e->shm_pinned ? 1 : 0; }
 // The mirror of a pipe whose counters the HOST decides (a poisoned pipe: nc[*] = -1, ec[*] = 0)
 void IPCEnv_SetMirror(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t nc_fill, int32_t ec_fill)
 {
-    if (!e || !e->shm || dev_id < 0 || dev_id >= e->device_count) return;
+    if (!e || !e->ext || dev_id < 0 || dev_id >= e->device_count) return;
     const int q = current_pipe % e->pipeline_depth;
-    for (int i = 0; i < 16; i++) { e->shm->ext_counters[dev_id][q][i] = nc_fill; e->shm->ext_counters[dev_id][q][16 + i] = ec_fill; }
+    for (int i = 0; i < 16; i++) { e->ext->counters[dev_id][q][i] = nc_fill; e->ext->counters[dev_id][q][16 + i] = ec_fill; }
     if (e->mirror_stage[dev_id][q]) for (int i = 0; i < 32; i++) e->mirror_stage[dev_id][q][i] = i < 16 ? nc_fill : ec_fill;
     e->mirror_fresh[dev_id][q] = true;
 }
 void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe)
 {
     const int q = current_pipe % e->pipeline_depth;
-    if (e->shm && e->mirror_fresh[dev_id][q] && !e->shm_pinned && e->mirror_stage[dev_id][q])     // staged by a queued copy the caller has waited for
-        for (int i = 0; i < 32; i++) e->shm->ext_counters[dev_id][q][i] = e->mirror_stage[dev_id][q][i];
-    if (e->shm && e->shm->ext_mirror_magic == kMirrorMagic && !e->mirror_fresh[dev_id][q] && !e->node_counter[dev_id].empty() && !no_device()) {
+    if (e->ext && e->mirror_fresh[dev_id][q] && !e->shm_pinned && e->mirror_stage[dev_id][q])     // staged by a queued copy the caller has waited for
+        for (int i = 0; i < 32; i++) e->ext->counters[dev_id][q][i] = e->mirror_stage[dev_id][q][i];
+    if (e->ext && e->ext->mirror_magic == kMirrorMagic && !e->mirror_fresh[dev_id][q] && !e->node_counter[dev_id].empty() && !no_device()) {
         // a producer that did not queue the mirror copy (a reference-style RunOnce on this library): copy now -- the batch is
         // complete when a pipe is posted, so a blocking copy is correct, merely slower than the queued one
         DeviceGuard guard(dev_id);
         int32_t h[32];
         if (hipMemcpy(h, e->node_counter[dev_id][q], 64, hipMemcpyDeviceToHost) == hipSuccess &&
             hipMemcpy(h + 16, e->edge_counter[dev_id][q], 64, hipMemcpyDeviceToHost) == hipSuccess)
-            for (int i = 0; i < 32; i++) e->shm->ext_counters[dev_id][q][i] = h[i];
-        else { (void)hipGetLastError(); e->shm->ext_mirror_magic = 0; }   // clients fall back to the device buffers
+            for (int i = 0; i < 32; i++) e->ext->counters[dev_id][q][i] = h[i];
+        else { (void)hipGetLastError(); e->ext->mirror_magic = 0; }   // clients fall back to the device buffers
     }
     e->mirror_fresh[dev_id][q] = false;
     if (e->semw[dev_id][q]) sem_post(e->semw[dev_id][q]);
@@ -621,17 +638,18 @@ void IPCEnv_Finalize(IPCEnv* e)
     for (VmmRegion* r : e->vmm) { DeviceGuard guard(r->device); vmm_release(r); }
     e->vmm.clear();
     if (e->shm) {
-        if (e->shm_pinned) { (void)hipHostUnregister((void*)e->shm); e->shm_pinned = false; }
+        if (e->shm_pinned && e->ext) { (void)hipHostUnregister((void*)e->ext); e->shm_pinned = false; }
         for (auto& dev : e->mirror_stage) for (auto& p : dev) if (p) { (void)hipHostFree(p); p = nullptr; }
         munmap((void*)e->shm, sizeof(shmStruct));
         close(e->shm_fd);
         shm_unlink(shm_name().c_str());
         e->shm = nullptr;
+        if (e->ext) { munmap((void*)e->ext, sizeof(shmExt)); close(e->ext_fd); shm_unlink(ext_name().c_str()); e->ext = nullptr; }
     }
 }
 
 int32_t IPCEnv_GetTrainStep(IPCEnv* e) { return e->train_step; }
-void IPCEnv_SetHops(IPCEnv* e, int32_t hops) { if (e && e->shm) e->shm->ext_hops = hops; }
+void IPCEnv_SetHops(IPCEnv* e, int32_t hops) { if (e && e->ext) e->ext->hops = hops; }
 
 } // extern "C"
 
@@ -639,6 +657,8 @@ void IPCEnv_SetHops(IPCEnv* e, int32_t hops) { if (e && e->shm) e->shm->ext_hops
 struct LegionIPCClient {
     volatile shmStruct* shm = nullptr;
     int shm_fd = -1;
+    volatile shmExt* ext = nullptr;    // null: the server has no extension object (a reference server): hops = 2, counters by device copy
+    int ext_fd = -1;
     int device = 0;
     void* buf[LEGION_PIPELINE_DEPTH][LEGION_MEMORY_USAGE] = {};
     sem_t* semr[LEGION_PIPELINE_DEPTH] = {};
@@ -723,8 +743,9 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
     if (device_id < 0 && getenv("LEGION_IPC_DEVICE")) c->device = atoi(getenv("LEGION_IPC_DEVICE"));
     c->shm = (volatile shmStruct*)shm_map(sizeof(shmStruct), &c->shm_fd);
     if (!c->shm) { fprintf(log_file(), "Failed to create shared memory slab\n"); delete c; LEGION_ARG_ERROR("legion_ipc_client_open: shm"); return nullptr; }
+    c->ext = (volatile shmExt*)shm_map(sizeof(shmExt), &c->ext_fd, ext_name(), false);     // never created by a client
     for (int i = 0; i < 3; i++) c->steps[i] = c->shm->steps[i];
-    c->hops = c->shm->ext_hops > 0 ? c->shm->ext_hops : 2;
+    c->hops = (c->ext && c->ext->hops > 0) ? c->ext->hops : 2;
     if (c->device >= LEGION_MAX_DEVICE) { LEGION_ARG_ERROR("legion_ipc_client_open: device id >= 8"); delete c; return nullptr; }
     for (int i = 0; i < LEGION_PIPELINE_DEPTH; i++) {
         for (int w = 0; w < LEGION_MEMORY_USAGE; w++) {
@@ -789,12 +810,12 @@ void legion_ipc_client_steps(LegionIPCClient* c, int32_t steps[3])
     for (int i = 0; i < 3; i++) steps[i] = c->steps[i];
 }
 int32_t legion_ipc_client_hops(LegionIPCClient* c) { return c->hops; }
-int32_t legion_ipc_client_feature_rows(LegionIPCClient* c) { return (c && c->shm) ? c->shm->ext_feature_rows[c->device] : 0; }
+int32_t legion_ipc_client_feature_rows(LegionIPCClient* c) { return (c && c->ext) ? c->ext->feature_rows[c->device] : 0; }
 void legion_ipc_client_read_counters(LegionIPCClient* c, int32_t h_node_counter[16], int32_t h_edge_counter[16])
 {
-    if (c->shm->ext_mirror_magic == kMirrorMagic) {
+    if (c->ext && c->ext->mirror_magic == kMirrorMagic) {
         // the server's host mirror of this pipe: no device copy, no implicit synchronisation with the trainer's own GPU work
-        const volatile int32_t* m = &c->shm->ext_counters[c->device][c->current_pipe][0];
+        const volatile int32_t* m = &c->ext->counters[c->device][c->current_pipe][0];
         for (int i = 0; i < 16; i++) { h_node_counter[i] = m[i]; h_edge_counter[i] = m[16 + i]; }
         return;
     }
@@ -819,6 +840,7 @@ void legion_ipc_client_close(LegionIPCClient* c)
         if (c->semr[i] && c->semr[i] != SEM_FAILED) sem_close(c->semr[i]);
     }
     if (c->shm) { munmap((void*)c->shm, sizeof(shmStruct)); close(c->shm_fd); }
+    if (c->ext) { munmap((void*)c->ext, sizeof(shmExt)); close(c->ext_fd); }
     delete c;
 }
 

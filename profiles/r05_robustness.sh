@@ -38,8 +38,8 @@ else echo "   CONTROL FAILED: the sanitizer did not report the overflow"; rc=1; 
 echo "== 1. tests/abi_null_args.py"; python tests/abi_null_args.py | tail -n 3 || rc=1
 echo "== 2. tests/ipc_env_cpu.py (producer + 2 consumers + poisoned pipe + stale semaphores)"; python tests/ipc_env_cpu.py producer "rb$$_" | grep PRODUCER_OK || rc=1
 export LEGION_SERVER_BIN=$PWD/legion-1_amd/csrc/asan/legion_asan      # the server binary itself under the sanitizers: argv + meta_config parsing and refusals
-echo "== 3. pytest: host logic, symbol table, IPC env on the CPU, oracle-vs-host-side comparisons"
-python -m pytest tests/test_host_logic.py tests/test_capi_symbols.py tests/test_ipc_env_cpu.py -q -p no:cacheprovider 2>&1 | tail -n 6 || rc=1
+echo "== 3. pytest: host logic, symbol table, IPC env on the CPU, the slab against the reference's own shm helper (oracle/_ref)"
+python -m pytest tests/test_host_logic.py tests/test_capi_symbols.py tests/test_ipc_env_cpu.py tests/test_ref_shm_compat.py -q -p no:cacheprovider 2>&1 | tail -n 6 || rc=1
 echo "== apart from the control in step 0, 'ERROR: AddressSanitizer' / 'runtime error:' must not occur in this log"
 echo "== exit status $rc"
 exit $rc

@@ -209,7 +209,7 @@ def _client_open_without_listener(tmp_ns):
     L.legion_set_error_mode(K.ERR_RETURN)
     L.legion_clear_error()
     L.legion_ipc_set_namespace(tmp_ns.encode())
-    size = 12 + 8 * 2 * 7 * 64 + 4
+    size = 12 + 8 * 2 * 7 * 64            # exactly the reference's struct: nothing is appended to the shared slab
     path = "/dev/shm/" + tmp_ns + "simpleIPCshm"
     desc = b"LGNVMM01" + struct.pack("<QQII", 1 << 21, 1 << 21, 1, 0)
     slab = bytearray(size)

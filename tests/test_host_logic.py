@@ -365,3 +365,29 @@ def test_runner_gather_choice_at_the_baseline_shapes():
         assert L.legion_runner_gather_estimate(F, rows, slots, C.byref(g), C.byref(s_)) == want, (name, g.value, s_.value)
         assert g.value > 0 and s_.value > 0
     assert L.legion_runner_gather_estimate(128, 0.0, 0.0, None, None) == 0          # no pre-sampled batch: the reference's list
+
+
+def test_launcher_against_the_references_own_launcher(tmp_path, monkeypatch):
+    """tests/golden/launcher_lines.json was produced by the REFERENCE's legion_server.py (imported in the build container, os.system recorded instead of
+    run: `python oracle/make_golden_launcher.py`): the `meta_config` line and the server command for 6 datasets x 4 GPU counts x both interconnect
+    switches x 2 (batch, cache, epoch) settings.  launch_server.py must write the same line and start its server with the same <gpu_number>
+    <cache_agg_mode>, for the same command line."""
+    import importlib.util
+    g = load_golden("launcher_lines")
+    assert len(g["cases"]) == 96
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("launch_server", os.path.join(root, "legion-1_amd", "launch_server.py"))
+    ls = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ls)
+    monkeypatch.chdir(tmp_path)
+    printed = []
+    monkeypatch.setattr("builtins.print", lambda *a, **k: printed.append(" ".join(map(str, a))))
+    for c in g["cases"]:
+        del printed[:]
+        rc = ls.main(["--dataset_path", c["dataset_path"], "--dataset", c["dataset"], "--train_batch_size", str(c["train_batch_size"]), "--gpu_number", str(c["gpu_number"]),
+                      "--epoch", str(c["epoch"]), "--cache_memory", str(c["cache_memory"]), "--usenvlink", str(c["usenvlink"]), "--dry_run"])
+        assert rc == 0
+        assert open("meta_config").read() == c["meta_config"], c
+        ours, theirs = printed[-1].split(), c["command"].split()
+        assert ours[0].endswith("legion") and theirs[0].endswith("legion") and ours[1:3] == theirs[1:3], (ours, theirs)
+        assert ours[3] == "25,10" and ours[4] == os.path.abspath("meta_config")     # the two extras: fan-outs (the reference hard-codes 25,10), the file it just wrote

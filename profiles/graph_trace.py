@@ -81,23 +81,32 @@ def main():
     ap.add_argument("--fanout", default="25,10")
     ap.add_argument("--epochs", type=int, default=20)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "graph_trace"))
-    ap.add_argument("--variants", default="plain,graph1,graph2,graph3")
+    ap.add_argument("--variants", default="plain,graph1,graph2,graph3",
+                    help="plain (LEGION_RUNNER_GATHER=auto) | level | all (the plain loop with that gather formulation, round 5) | graph1 | graph2 | graph3")
+    ap.add_argument("--source", default="files", choices=["files", "synth"], help="synth: the server generates the tables (meta_config `synth:<workload>:<scale>`): full shapes")
     a = ap.parse_args()
     a.out = os.path.abspath(a.out)
     import dataclasses
     import legion1_amd.synth as S
-    ds = S.generate(S.spec_for(a.workload, scale=a.scale))
-    ds.valid, ds.test = ds.valid[:512], ds.test[:512]
-    ds.spec = dataclasses.replace(ds.spec, n_valid=len(ds.valid), n_test=len(ds.test))
     tmp = tempfile.mkdtemp(prefix="legion_gt_")
-    data = os.path.join(tmp, "ds") + "/"
-    S.write_legion_files(ds, data)
     meta = os.path.join(tmp, "meta_config")
-    with open(meta, "w") as f:
-        f.write(S.meta_config_line(ds, data, a.batch, 1 << 40, a.epochs, 0))
+    if a.source == "synth":
+        spec = S.spec_for(a.workload, scale=a.scale)
+        with open(meta, "w") as f:
+            f.write("synth:%s:%r %d %d 0 %d %d 512 512 0 %d 0" % (a.workload, a.scale, a.batch, spec.V, spec.F, spec.n_train, a.epochs))
+    else:
+        ds = S.generate(S.spec_for(a.workload, scale=a.scale))
+        ds.valid, ds.test = ds.valid[:512], ds.test[:512]
+        ds.spec = dataclasses.replace(ds.spec, n_valid=len(ds.valid), n_test=len(ds.test))
+        data = os.path.join(tmp, "ds") + "/"
+        S.write_legion_files(ds, data)
+        with open(meta, "w") as f:
+            f.write(S.meta_config_line(ds, data, a.batch, 1 << 40, a.epochs, 0))
     server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
     hops = len(a.fanout.split(","))
-    for name, extra, traced in (("plain", {}, False), ("graph1", {"LEGION_BATCH_GRAPH": "1"}, False), ("graph2", {"LEGION_BATCH_GRAPH": "2"}, False), ("graph3", {"LEGION_BATCH_GRAPH": "3"}, False),
+    for name, extra, traced in (("level", {"LEGION_RUNNER_GATHER": "level"}, False), ("all", {"LEGION_RUNNER_GATHER": "all"}, False),
+                                ("level", {"LEGION_RUNNER_GATHER": "level"}, True), ("all", {"LEGION_RUNNER_GATHER": "all"}, True),
+                                ("plain", {}, False), ("graph1", {"LEGION_BATCH_GRAPH": "1"}, False), ("graph2", {"LEGION_BATCH_GRAPH": "2"}, False), ("graph3", {"LEGION_BATCH_GRAPH": "3"}, False),
                                 ("plain", {}, True), ("graph1", {"LEGION_BATCH_GRAPH": "1"}, True), ("graph2", {"LEGION_BATCH_GRAPH": "2"}, True), ("graph3", {"LEGION_BATCH_GRAPH": "3"}, True)):
         if name not in a.variants.split(","):
             continue

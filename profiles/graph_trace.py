@@ -36,6 +36,7 @@ def analyse(d, hops):
     # batches: from one k_seed to the next; steady state = full training batches (the most common kernel count)
     starts = [i for i, k in enumerate(ks) if k[2] == "k_seed"]
     batches = [ks[a:b] for a, b in zip(starts, starts[1:])]
+    batches = [b for b in batches if not any(k[2] == "k_hotness" for k in b)]      # the pre-sampling epoch (sampler + k_hotness, one stream) is not steady state
     common = collections.Counter(len(b) for b in batches).most_common(1)[0][0]
     batches = [b for b in batches if len(b) == common]
     batches = batches[min(20, len(batches) // 4):len(batches) - 2]

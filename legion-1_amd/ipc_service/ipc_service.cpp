@@ -100,11 +100,13 @@ int get_hops() { return g_hops; }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
-    m.def("get_next", &get_next, "dataset get next (HIP)");
+    // get_next blocks on the pipe's semaphore and synchronize on the trainer's device: neither touches Python state, so both run without the GIL
+    // (the reference holds it: a trainer's other Python threads stall for as long as the server takes to produce a batch)
+    m.def("get_next", &get_next, "dataset get next (HIP)", pybind11::call_guard<pybind11::gil_scoped_release>());
     m.def("get_block_size", &get_block_size, "get dgl block size");
     m.def("get_steps", &get_steps, "get steps");
     m.def("initialize", &InitializeIPC, "InitializeIPC");
     m.def("finalize", &FinalizeIPC, "FinalizeIPC");
-    m.def("synchronize", &Synchronize, "synchronize");
+    m.def("synchronize", &Synchronize, "synchronize", pybind11::call_guard<pybind11::gil_scoped_release>());
     m.def("get_hops", &get_hops, "number of hops the server samples (extension)");
 }

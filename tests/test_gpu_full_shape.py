@@ -346,9 +346,11 @@ def test_synth_server_serves_the_headline_shape(K, oracle, synth, tmp_path):
     B, fan, H = case["batch"], case["fanout"], 3
     spec = synth.spec_for("papers100M")
     n_eval = 512
+    # soak (profiles/r05_runs_soak.sh): LEGION_TEST_EPOCHS=3 LEGION_TEST_SERVED_EVERY=97 also checks every 97th served batch of three epochs
+    epochs, every = int(os.environ.get("LEGION_TEST_EPOCHS", "1")), int(os.environ.get("LEGION_TEST_SERVED_EVERY", "0"))
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
-        f.write("synth:papers100M %d %d %d %d %d %d %d 0 1 0" % (B, spec.V, case["E"], spec.F, spec.n_train, n_eval, n_eval))
+        f.write("synth:papers100M %d %d %d %d %d %d %d 0 %d 0" % (B, spec.V, case["E"], spec.F, spec.n_train, n_eval, n_eval, epochs))
     env = dict(os.environ, LEGION_IPC_NAMESPACE="fs%d_" % os.getpid(), HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_CLIENT_DUMP_IDS="1")
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:
@@ -357,14 +359,19 @@ def test_synth_server_serves_the_headline_shape(K, oracle, synth, tmp_path):
     train_step = (spec.n_train - 1) // B
     record = [0, train_step // 2, train_step - 1, train_step, train_step + 1]
     assert record[1] == 694
+    total = (train_step + 1) * epochs + 1
+    if epochs > 1:
+        record = [0, train_step // 2, train_step - 1, train_step, total - 1]        # the test batch comes behind the last epoch
+    soak = sorted(set(range(0, total, every)) - set(record)) if every > 0 else []
+    record = sorted(record + soak)
     try:
         t0 = time.time()
         while "System is ready for serving" not in open(log, errors="ignore").read():
             assert server.poll() is None, open(log).read()[-3000:]
             assert time.time() - t0 < 300, open(log).read()[-3000:]
             time.sleep(0.2)
-        client = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ipc_client_plain.py"), str(spec.F), "1", out, ",".join(map(str, record))],
-                                env=env, capture_output=True, text=True, timeout=600)
+        client = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ipc_client_plain.py"), str(spec.F), str(epochs), out, ",".join(map(str, record))],
+                                env=env, capture_output=True, text=True, timeout=1000)
         assert client.returncode == 0, client.stdout[-2000:] + client.stderr[-3000:]
         server.wait(timeout=120)
         assert server.returncode == 0, open(log).read()[-3000:]
@@ -375,6 +382,7 @@ def test_synth_server_serves_the_headline_shape(K, oracle, synth, tmp_path):
     assert "Graph generated in HBM: %d edges" % case["E"] in text and "Train Steps: %d" % train_step in text
     got = json.load(open(out))
     assert got["steps"] == [train_step, 1, 1] and got["hops"] == H and [r["b"] for r in got["batches"]] == record
+    per = train_step + 1
     # the oracle side: the CSR from the independent C generator on the host (oracle/synth_gen.c, OpenMP)
     h_indptr, h_indices = oracle.synth_csr(spec)
     assert int(h_indptr[-1]) == case["E"] and sha(h_indptr) == case["indptr_sha256"]
@@ -382,11 +390,15 @@ def test_synth_server_serves_the_headline_shape(K, oracle, synth, tmp_path):
     n1, n2 = spec.n_train, spec.n_train + spec.n_valid
     sets = {0: synth.seed_ids(spec, 0, n1), 1: synth.seed_ids(spec, n1, n1 + n_eval), 2: synth.seed_ids(spec, n2, n2 + n_eval)}
     assert sha(sets[0]) == case["seeds_sha256"]
+    labs = {m: synth.labels(spec, ids) for m, ids in sets.items()}
     golden = {w["counter"]: w for w in case["batches"]}
     for rec in got["batches"]:
-        mode, local = (0, rec["b"]) if rec["b"] < train_step else ((1, 0) if rec["b"] == train_step else (2, 0))
+        if rec["b"] >= per * epochs:
+            mode, local = 2, 0
+        else:
+            mode, local = (0, rec["b"] % per) if rec["b"] % per < train_step else (1, 0)
         ids = sets[mode]
-        ref = orc.run_batch(ids, synth.labels(spec, ids), local, mode=mode, batch_size=B if mode == 0 else n_eval, gather=False, omp=(mode == 0))
+        ref = orc.run_batch(ids, labs[mode], local, mode=mode, batch_size=B if mode == 0 else n_eval, gather=False, omp=(mode == 0))
         assert rec["nc"] == ref["nc"].tolist() and rec["ec"] == ref["ec"].tolist(), rec["b"]
         assert rec["ids"] == sha(ref["ids"]) and rec["labels"] == sha(ref["labels"]), rec["b"]
         assert rec["src"] == sha(ref["src_off"]) and rec["dst"] == sha(ref["dst_off"]), rec["b"]
@@ -396,6 +408,8 @@ def test_synth_server_serves_the_headline_shape(K, oracle, synth, tmp_path):
             assert rec["ids"] == w["ids_sha256"] and rec["src"] == w["src_off_sha256"] and rec["dst"] == w["dst_off_sha256"] and rec["labels"] == w["labels_sha256"]
         served_ids = np.load(out + ".ids%d.npy" % rec["b"])
         assert np.array_equal(served_ids, ref["ids"])
+        if rec["b"] in soak and soak.index(rec["b"]) % 4:      # soak batches: the rows of every fourth one against the closed form
+            continue
         h = hashlib.sha256()
         for r0 in range(0, len(served_ids), 1 << 16):
             h.update(np.ascontiguousarray(synth.features(spec, served_ids[r0:r0 + (1 << 16)])).tobytes())

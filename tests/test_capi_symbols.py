@@ -96,3 +96,24 @@ def test_c_abi_survives_null_arguments():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi_null_args.py")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "survived" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert "NewIPCEnv: device_count must be 1..8" in r.stdout and "GPUGraphStorage_Build: null argument" in r.stdout
+
+
+def test_ipc_service_module_has_the_surface_the_reference_trainers_call():
+    """tests/golden/trainer_api.json: every `ipc_service.<name>(...)` call of the reference's three trainer scripts with its argument count and the number of
+    values the script unpacks (extracted from their source by the Python parser: `python oracle/make_golden_trainer_api.py`; the scripts need dgl and cannot be
+    imported).  The drop-in module must export exactly that surface with those arities; the counts returned at 2 hops (7 tensors, 4 sizes, 3 steps) are checked
+    against the served batches in tests/test_gpu_ipc.py."""
+    import json
+    import sys
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "trainer_api.json")))
+    assert g["surface"] == {"finalize": [[0, None]], "get_block_size": [[0, 4]], "get_next": [[1, 7]], "get_steps": [[0, 3]], "initialize": [[0, None]], "synchronize": [[0, None]]}
+    assert [len(v) for v in g["scripts"].values()] == [12, 12, 12]      # twelve call sites in each of the three scripts
+    sys.path.insert(0, os.path.join(ROOT, "legion-1_amd", "ipc_service"))
+    import torch  # noqa: F401  (the extension links libtorch)
+    import ipc_service
+    for name, sigs in g["surface"].items():
+        fn = getattr(ipc_service, name)
+        (n_args, _), = sigs
+        doc = fn.__doc__.splitlines()[0]                              # pybind11 signature line: name(arg0: int) -> ...
+        params = doc[doc.index("(") + 1:doc.index(")")].strip()
+        assert (len(params.split(",")) if params else 0) == n_args, (name, doc)

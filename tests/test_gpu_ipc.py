@@ -68,6 +68,11 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
     got = json.load(open(out))
     H = len(fan)
     assert got["hops"] == H
+    if H == 2:      # what the reference's trainers unpack (tests/golden/trainer_api.json, extracted from their source): 7 tensors, 4 block sizes, 3 step counts
+        api = json.load(open(os.path.join(ROOT, "tests", "golden", "trainer_api.json")))["surface"]
+        rec0 = got["batches"][0]
+        assert 3 + 2 * len(rec0["edges"]) == api["get_next"][0][1] == 7 and len(rec0["sizes"]) == api["get_block_size"][0][1] == 4
+        assert len(got["steps"]) == api["get_steps"][0][1] == 3
     sets = {0: ds.train, 1: ds.valid, 2: ds.test}
     steps, tb, vb, sb = oracle.coordinate([len(ds.train)], [len(ds.valid)], [len(ds.test)], B)
     assert got["steps"] == steps.tolist()

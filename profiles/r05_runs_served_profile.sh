@@ -16,7 +16,7 @@ wait $SRV
 python3 - $O <<'PY'
 import csv, glob, json, sys
 o = sys.argv[1]
-d = json.load(open(o + "/consumer.json"))
+d = json.loads(open(o + "/consumer.json").read().strip().splitlines()[-1])      # (the library prints "IPC shared memory opened" first)
 t = d["t"]; ts = d["steps"][0]
 print("served: %d batches, %.4f ms per training batch over epoch 2 (consumer clock)" % (len(t), (t[2 * ts] - t[ts + 1]) / (ts - 1) * 1e3))
 f = glob.glob(o + "/prof/*/*kernel_stats.csv")[0]

@@ -595,6 +595,11 @@ def extra_leg(c, name):
     if name == "served":
         return served_leg(c, c.args.workload, c.fan, c.head)
     if name == "served_all":
+        # the last leg: every rank gives its graph back first (uk-union: 160 GB per GPU), the server generates its own replica on every GPU
+        import torch
+        for k in ("indptr", "indices", "feats", "mine", "my_labels"):
+            setattr(c, k, None)
+        torch.cuda.empty_cache()
         return served_all_leg(c) if c.rank == 0 else None
     if name == "lp":
         # lp_sage.py:87-90: [src | pos | neg] seed thirds; triples dealt to the ranks by src % N; the graph is the headline's

@@ -337,7 +337,11 @@ def test_server_binary_refuses_a_malformed_meta_config(tmp_path):
              ("/d/ 8 100 -5 16 10 10 10 0 1 0", "negative edge count"), ("/d/ 8 100 1000 0 10 10 10 0 1 0", "feature dim < 1"),
              ("/d/ 8 100 1000 16 -1 10 10 0 1 0", "negative seed-set size"), ("/d/ 8 100 1000 16 101 10 10 0 1 0", "larger than the node count"),
              ("/d/ 8 100 1000 16 10 10 10 -1 1 0", "negative cache budget"), ("/d/ 8 100 1000 16 10 10 10 0 -2 0", "negative epoch count"),
-             ("/d/ 8 100 1000 16 10 10 10 0 1 3", "partition flag outside 0..2"), ("synth:nothing 8 100 0 16 10 10 10 0 1 0", "names no known workload")]
+             ("/d/ 8 100 1000 16 10 10 10 0 1 3", "partition flag outside 0..2"), ("synth:nothing 8 100 0 16 10 10 10 0 1 0", "names no known workload"),
+             # a synth: source whose meta line is not the generator's (products at 0.4 %: V = 9796, F = 100, 786 training ids) -- refused before any device call
+             ("synth:products:0.004 8 9797 0 100 10 10 10 0 1 0", "differ from the synth: generator's"), ("synth:products:0.004 8 9796 0 64 10 10 10 0 1 0", "differ from the synth: generator's"),
+             ("synth:products:0.004:300 8 9796 0 100 10 10 10 0 1 0", "differ from the synth: generator's"), ("synth:products:0.004 8 9796 0 100 787 10 10 0 1 0", "larger than the synth: generator's"),
+             ("synth:products:7 8 9796 0 100 10 10 10 0 1 0", "names no known workload")]
     for line, want in cases:
         meta = tmp_path / "meta_config"
         meta.write_text(line)

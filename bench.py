@@ -376,6 +376,9 @@ def worker(args):
             emit_line(line)
         raise
     if rank == 0:
+        sv = line["extra_legs"].get("served") or {}
+        if isinstance(sv, dict) and sv.get("value"):      # the headline batches as a trainer sees them, next to `value` (serial) and `value_overlap` (two streams, in-process)
+            line["value_served"], line["ms_per_step_served"] = sv["value"], sv["ms_per_step"]
         line["time_budget"] = {"budget_s": args.time_budget, "used_s": round(time.time() - c.budget.t0, 1)}
         emit_line(line)
     if world > 1:
@@ -1481,6 +1484,7 @@ def headline_line(c, leg):
         # the two-stream schedule the `legion` server runs (gather of batch i on stream 1 while batch i+1 is sampled), same
         # batches, median of its own windows: the best number the pipeline produces; `value` stays the serial schedule, whose
         # kernels run alone and give the clean per-kernel roofline
+        "value_served": None, "ms_per_step_served": None,      # filled from extra_legs.served (N = 1): the `legion` server binary + a consumer process
         "value_overlap": (leg["alt"] or {}).get("value") if (leg["alt"] or {}).get("pipeline") == "overlap" else None,
         "ms_per_step_overlap": (leg["alt"] or {}).get("ms_per_step") if (leg["alt"] or {}).get("pipeline") == "overlap" else None,
         "alt_schedule": leg["alt"],

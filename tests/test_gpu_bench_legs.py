@@ -98,6 +98,7 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     assert sv["schedule"]["train_steps"] == (int(11105995 * 0.02) - 1) // 8000 and sv["schedule"]["epochs"] >= 2
     assert sv["served_batches_equal_the_timed_ones"] is True and sv["server_tables"] == "generated in HBM"
     assert sv["ratio_to_alt_schedule_levels"] > 0 and sv["fanout"] == [25, 10, 5] and sv["F"] == 128
+    assert line["value_served"] == sv["value"] and line["ms_per_step_served"] == sv["ms_per_step"]        # also at the top level, next to value / value_overlap
     for name, leg in legs.items():
         assert leg.get("error") is None and leg["value"] > 0 and leg["ms_per_step"] > 0, (name, leg)
         assert 0 < leg["gather_frac_of_hbm_peak"] < 1 and leg["sampler_us_per_batch"] > 0 and 0 < leg["pipeline_frac"] < 1, (name, leg)

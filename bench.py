@@ -625,6 +625,12 @@ def extra_leg(c, name):
         out = leg_summary(c2, leg, f"headline graph and batches; the hottest {a.cache_frac:.0%} of the feature rows in a cache shard (Kg = {c.world}), every row "
                                    "resolved by FindFeat (k_row_ptrs: id -> slot -> shard row / table row) in front of the gather, misses from the HBM table")
         out["gather_launch_includes"] = "k_row_ptrs + k_gather (HIP events around get_feature_kernel)"
+        if c.world == 1 and c.budget.left() > 90.0:
+            try:      # the cached path as a trainer sees it: the server builds its cache with a budget of cache_frac of the feature table ($LEGION_SYNTH_CACHE=1;
+                      # the cost model splits it between adjacency rows and feature rows: sampler over CSR fragments + cached gather)
+                out["served"] = served_leg(c2, c.args.workload, c2.fan, leg, cache_bytes=int(c.spec.V * c.spec.F * 4 * a.cache_frac))
+            except Exception as ex:   # noqa: BLE001 -- the leg's own numbers stay valid
+                out["served"] = {"error": repr(ex)[:300]}
         return out
     if name in ("products_2hop", "products_3hop"):
         if not c.spec.name.startswith("products"):
@@ -722,7 +728,7 @@ def served_schedule_windows(t, train_step, valid_step, epochs, K_steps, warm):
     return out
 
 
-def served_leg(c, workload, fan, ref_leg, lp=False):
+def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
     """The whole path through the reference's surface, as a trainer sees it: the `legion` server binary -- started as a
     FRESH child process, dataset source `synth:<workload>` (the tables generated in its own HBM by the legion_synth_* calls this file uses),
     pre-sampling epoch, then its default software-pipelined RunOnce loop (runner.cpp; Server.cu:301-328) -- hands every batch of its schedule
@@ -757,8 +763,10 @@ def served_leg(c, workload, fan, ref_leg, lp=False):
     src = "synth:%s" % workload + ("" if (args.scale == 1.0 and args.skew == 205) else ":%r" % args.scale) + ("" if args.skew == 205 else ":%d" % args.skew)
     meta = os.path.join(tmp, "meta_config")
     with open(meta, "w") as f:
-        f.write("%s %d %d 0 %d %d %d %d 0 %d %d" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, epochs, 2 if lp else 0))
+        f.write("%s %d %d 0 %d %d %d %d %d %d %d" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, int(cache_bytes), epochs, 2 if lp else 0))
     env = dict(os.environ, LEGION_IPC_NAMESPACE="bs%d_%d_" % (os.getpid(), len(c.children)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if cache_bytes > 0:
+        env["LEGION_SYNTH_CACHE"] = "1"      # build the hotness cache on top of the generated tables: cost model, FillUp, cached gather / partitioned sampler
     env.pop("LEGION_LOG", None)          # the server's log is its stdout (a file here), as with the reference
     if c.local_rank != 0:
         env["HIP_VISIBLE_DEVICES"] = str(c.local_rank)
@@ -833,6 +841,7 @@ def served_leg(c, workload, fan, ref_leg, lp=False):
             "pipeline_frac": round(float(ref_leg["job_bytes"]) / args.steps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ref_leg
                              else round(n_mean * (8 * spec.F + 8) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "server_ready_s": round(ready_s, 2), "server_tables": "generated in HBM" if "Tables generated in HBM" in log_text else "?",
+            "server_cache": next((ln.strip() for ln in log_text.splitlines() if ln.startswith("Feat capacity")), None) if cache_bytes > 0 else None,
             "server_first_epoch_s": next((float(ln.split(":")[1].split()[0]) for ln in log_text.splitlines() if ln.startswith("First epoch cost")), None),
             "processes": "bench.py (idle) + legion + consumer"}
 

@@ -722,8 +722,11 @@ void Server_Initialize(Server* s, int global_shard_count)
                 }
             }
             s->noder->replica_pitch = s->synth_pitch;
-            s->replicated = true;
-            log_out() << "Tables generated in HBM: " << need / 1e9 << " GB per GPU\n";
+            // $LEGION_SYNTH_CACHE=1: build the hotness cache anyway (budget = the meta line's cache_memory), as if the generated tables were the
+            // reference's host tables -- the cost model, FillUp and the cached gather / partitioned sampler through the server binary on a
+            // synth: source (bench.py's `cached_gather.served`, tests).  Default: everything is already HBM resident, a cache has nothing to add.
+            { const char* e = getenv("LEGION_SYNTH_CACHE"); s->replicated = !(e && e[0] == '1'); }
+            log_out() << "Tables generated in HBM: " << need / 1e9 << " GB per GPU" << (s->replicated ? "" : " (cache built on top: LEGION_SYNTH_CACHE=1)") << "\n";
         } else if (replicate) {
             GPUGraphStorage_ReplicateToDevices(s->graph);
             GPUNodeStorage_ReplicateToDevices(s->noder);

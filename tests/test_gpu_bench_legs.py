@@ -108,6 +108,8 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     cg = legs["cached_gather"]
     assert cg["Kg"] == 1 and 0.2 < cg["cached_fraction_of_V"] < 0.3 and cg["F"] == 128
     assert min(cg["rows_last_batch"][k] for k in ("own_shard", "backing_table")) > 0 and cg["rows_last_batch"]["peer_shards"] == 0
+    cgs = cg["served"]     # the cached path through the server: cost model + FillUp + cached gather on a synth: source ($LEGION_SYNTH_CACHE=1)
+    assert cgs.get("error") is None and cgs["served_batches_equal_the_timed_ones"] is True and cgs["server_cache"].startswith("Feat capacity"), cgs
     p2, p3 = legs["products_2hop"], legs["products_3hop"]
     assert p2["fanout"] == [25, 10] and p3["fanout"] == [25, 10, 5] and p2["F"] == p3["F"] == 100
     assert p2["cpu_baseline"]["value"] > 0 and p2["cpu_baseline"]["dgl_semantics"]["value"] > 0 and "cpu_baseline" not in p3

@@ -95,7 +95,8 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
 
 
 @pytest.mark.parametrize("workload,scale,fan,B,G,gather", [("products", 0.004, [5, 4, 3], 512, 1, "auto"), ("papers100M", 0.0008, [25, 10], 1000, 1, "level"),
-                                                          ("uk-union", 0.0005, [10, 5], 512, 2, "all"), ("products", 0.004, [25, 10, 5], 512, 1, "auto")])
+                                                          ("uk-union", 0.0005, [10, 5], 512, 2, "all"), ("products", 0.004, [25, 10, 5], 512, 1, "auto"),
+                                                          ("products", 0.004, [10, 5], 512, 1, "cache-all"), ("papers100M", 0.0008, [10, 5], 512, 2, "cache-level")])
 def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, fan, B, G, gather):
     """meta_config dataset path `synth:<workload>:<scale>`: the server generates CSR + features in HBM with the legion_synth_* calls
     (no files) -- what bench.py's `served` leg starts at the papers100M shape.  Every served batch (train, valid, test) must equal the
@@ -106,11 +107,15 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
     n_valid, n_test = min(700, spec.n_valid), min(300, spec.n_test)                   # the meta line takes the first n ids of each range
     meta = str(tmp_path / "meta_config")
     with open(meta, "w") as f:
-        f.write("synth:%s:%r %d %d %d %d %d %d %d %d %d 0" % (workload, scale, B, spec.V, ds.E, spec.F, spec.n_train, n_valid, n_test, 1 << 40, epochs))
-    ns = "sy%d_%s%d_" % (os.getpid(), workload[:2], len(fan) + fan[0])
+        # cache-*: $LEGION_SYNTH_CACHE=1 with a budget of 20 % of the feature table -- cost model, FillUp, cached gather and partitioned sampler behind the server
+        budget = int(spec.V * spec.F * 4 * 0.2) if gather.startswith("cache") else 1 << 40
+        f.write("synth:%s:%r %d %d %d %d %d %d %d %d %d 0" % (workload, scale, B, spec.V, ds.E, spec.F, spec.n_train, n_valid, n_test, budget, epochs))
+    ns = "sy%d_%s%d%s_" % (os.getpid(), workload[:2], len(fan) + fan[0], gather[:2])
     # LEGION_RUNNER_GATHER: one FeatureExtractor op per level (the reference's op list) / one gather over all rows behind the last hop /
     # auto = decided once after the pre-sampling epoch from its counters -- the served batches are the same bytes either way
-    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_RUNNER_GATHER=gather)
+    env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", LEGION_RUNNER_GATHER=gather.replace("cache-", ""))
+    if gather.startswith("cache"):
+        env["LEGION_SYNTH_CACHE"] = "1"
     log = str(tmp_path / "server.log")
     with open(log, "w") as lf:
         server = subprocess.Popen([SERVER, str(G), "0", ",".join(map(str, fan)), meta], stdout=lf, stderr=subprocess.STDOUT, env=env, cwd=str(tmp_path))
@@ -135,6 +140,7 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
     text = open(log).read()
     assert "Graph generated in HBM: %d edges" % ds.E in text and "Tables generated in HBM" in text and "Server Stopped" in text
     assert ("Runner gather:" in text) == (gather == "auto")
+    assert ("cache built on top" in text and "Feat capacity" in text) == gather.startswith("cache")        # the cost model sized a real cache
     H = len(fan)
     parts = {0: oracle.split_seeds(ds.train, G), 1: oracle.split_seeds(ds.valid[:n_valid], G), 2: oracle.split_seeds(ds.test[:n_test], G)}
     steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)

@@ -713,6 +713,13 @@ def served_consumer(argv):
                                  "edges": edges, "nodes": nodes}) + "\n")
 
 
+def served_deadline(c):
+    """Seconds a served leg gives ITS child processes before it stops them and raises: well inside what the watchdog granted the leg, so that a
+    server or consumer that never comes back is a leg that FAILED (reported, exit code 0, the ranks stay in step) and not a leg that hung (exit code 3)."""
+    a = c.args
+    return time.time() + max(20.0, min(a.extra_timeout, c.budget.left() - Budget.RESERVE_S) - 25.0)
+
+
 def served_schedule_windows(t, train_step, valid_step, epochs, K_steps, warm):
     """Windows of K consecutive TRAINING batches inside one epoch of the served schedule (CUDA_IPC_Service.cu:219-259: every epoch is
     train_step training batches, then valid_step validation batches), the first `warm` training batches of every epoch left out: seconds per
@@ -772,6 +779,7 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
         env["HIP_VISIBLE_DEVICES"] = str(c.local_rank)
     log_path = os.path.join(tmp, "server.log")
     t0 = time.time()
+    deadline = served_deadline(c)
     srv = cons = None
     try:
         with open(log_path, "w") as lf:
@@ -780,15 +788,20 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
         while "System is ready for serving" not in open(log_path, errors="ignore").read():
             if srv.poll() is not None:
                 raise RuntimeError("the server exited before serving: " + open(log_path, errors="ignore").read()[-600:])
+            if time.time() > deadline:
+                raise RuntimeError("the server was not ready in time: " + open(log_path, errors="ignore").read()[-400:])
             time.sleep(0.05)
         ready_s = time.time() - t0
         cons = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--served-consumer", str(H), str(epochs)], env=env,
                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         c.children.append(cons)
-        out, err = cons.communicate()
+        try:
+            out, err = cons.communicate(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            raise RuntimeError("the consumer did not finish in time (server log: %s)" % open(log_path, errors="ignore").read()[-300:])
         if cons.returncode != 0:
             raise RuntimeError("the consumer failed (%d): %s" % (cons.returncode, (out + err)[-600:]))
-        srv.wait(timeout=60)
+        srv.wait(timeout=max(1.0, min(60.0, deadline + 10.0 - time.time())))
         if srv.returncode != 0:
             raise RuntimeError("the server failed (%d): %s" % (srv.returncode, open(log_path, errors="ignore").read()[-600:]))
         log_text = open(log_path, errors="ignore").read()
@@ -878,6 +891,7 @@ def served_all_leg(c):
         env.pop(k, None)
     log_path = os.path.join(tmp, "server.log")
     t0 = time.time()
+    deadline = served_deadline(c)
     srv, cons = None, []
     try:
         with open(log_path, "w") as lf:
@@ -886,6 +900,8 @@ def served_all_leg(c):
         while "System is ready for serving" not in open(log_path, errors="ignore").read():
             if srv.poll() is not None:
                 raise RuntimeError("the server exited before serving: " + open(log_path, errors="ignore").read()[-600:])
+            if time.time() > deadline:
+                raise RuntimeError("the server was not ready in time: " + open(log_path, errors="ignore").read()[-400:])
             time.sleep(0.05)
         ready_s = time.time() - t0
         for g in range(N):
@@ -895,11 +911,14 @@ def served_all_leg(c):
             c.children.append(p)
         outs = []
         for g, p in enumerate(cons):
-            out, err = p.communicate()
+            try:
+                out, err = p.communicate(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                raise RuntimeError("consumer %d did not finish in time (server log: %s)" % (g, open(log_path, errors="ignore").read()[-300:]))
             if p.returncode != 0:
                 raise RuntimeError("consumer %d failed (%d): %s" % (g, p.returncode, (out + err)[-500:]))
             outs.append(json.loads(out.strip().splitlines()[-1]))
-        srv.wait(timeout=60)
+        srv.wait(timeout=max(1.0, min(60.0, deadline + 10.0 - time.time())))
         if srv.returncode != 0:
             raise RuntimeError("the server failed (%d): %s" % (srv.returncode, open(log_path, errors="ignore").read()[-600:]))
         log_text = open(log_path, errors="ignore").read()

@@ -348,3 +348,21 @@ def test_served_schedule_windows_stay_inside_the_training_part_of_an_epoch():
         assert first - e * per >= warm and first + K <= e * per + ts          # inside the training part, behind the warm-up
         assert abs(secs - K * 0.001) < 1e-9                                    # K inter-arrival gaps; the late validation batch is outside
     assert bench.served_schedule_windows(t, ts, vs, epochs, 30, warm) == []    # a window longer than an epoch's training part: none
+
+
+def test_a_served_leg_stops_its_children_inside_the_watchdogs_grant():
+    """bench.served_deadline: a served leg's own deadline for its child processes lies 25 s inside min(--extra-timeout, what the budget leaves), never
+    less than 20 s from now: a server or consumer that never comes back becomes a FAILED leg (reported, exit code 0), not a hung one (exit code 3)."""
+    import time
+
+    class C:
+        pass
+    c = C()
+    c.args = bench.parse(["--extra-timeout", "150"])
+    clock = [1000.0]
+    c.budget = bench.Budget(480.0, t0=1000.0, now=lambda: clock[0])
+    assert abs((bench.served_deadline(c) - time.time()) - 125.0) < 1.0          # 150 - 25
+    clock[0] += 400.0                                                             # 80 s of the budget left: 80 - 15 - 25 = 40
+    assert abs((bench.served_deadline(c) - time.time()) - 40.0) < 1.0
+    clock[0] += 70.0                                                              # 10 s left: the floor
+    assert abs((bench.served_deadline(c) - time.time()) - 20.0) < 1.0

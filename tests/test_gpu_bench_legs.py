@@ -130,3 +130,13 @@ def test_a_symmetric_exchange_failure_does_not_cost_the_rest_of_the_line():
     u = line["unified_cache"]
     assert "injected failure of the exchange variant" in u["exchange_variant"]["error"] and u["value"] > 0 and u["Kg"] == 2
     assert line["legs_failed"] == [] and line["extra_legs"]["lp"]["value"] > 0 and line["extra_legs"]["uk_union"]["value"] > 0
+
+
+def test_served_all_failing_on_rank_0_costs_nothing_else():
+    """The one leg only rank 0 works in (it starts the server and the consumers; the other ranks wait in the agreement collective): a failure there --
+    a server that dies or is not ready inside the leg's own deadline -- is a FAILED leg, named in legs_failed, with every other leg intact and exit code 0."""
+    r, line = _bench({"LEGION_BENCH_INJECT_ERROR": "served_all:0"})
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    assert [f["leg"] for f in line["legs_failed"]] == ["served_all"] and line["legs_failed"][0]["hung"] is False
+    assert "error" in line["extra_legs"]["served_all"] and line["extra_legs"]["lp"]["value"] > 0 and line["extra_legs"]["uk_union"]["value"] > 0
+    assert line["unified_cache"]["value"] > 0 and line["value"] > 0

@@ -312,8 +312,6 @@ def worker(args):
     c.head_fan = list(c.fan)      # the headline's fan-out (later legs change c.fan on copies of the context)
     c.H = len(c.fan)
     c.B = args.batch
-    if args.row_pitch == "dense":
-        os.environ["LEGION_ROW_PITCH"] = "dense"      # cache shards too
     L.legion_set_device_map(0, local_rank)
     L.SetGPUDevice(0)
     load_workload(c, args.workload)
@@ -399,7 +397,7 @@ def load_workload(c, workload):
     c.spec = spec = S.spec_for(workload, scale=args.scale)
     V, F = spec.V, spec.F
     t0 = time.time()
-    c.pitch = L.legion_row_pitch(F) if args.table == "device" else F
+    c.pitch = L.legion_row_pitch(F) if (args.table == "device" and args.row_pitch != "dense") else F
     c.indptr, c.indices, c.feats, c.E = build_graph_on_gpu(K, spec, c.dev, args.skew, c.pitch)
     c.feat_ptr, c.feat_loc = c.feats.data_ptr(), K.LOC_DEVICE
     if args.table == "host":   # move the table to pinned, device-mapped host memory; misses then cross PCIe

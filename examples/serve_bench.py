@@ -1,12 +1,10 @@
 #!/usr/bin/env python3
 """Throughput of the `legion` server process as a trainer sees it: a null consumer (wait -> read counters -> post)
-drains every batch of the schedule through the C-ABI IPC client, for the three RunOnce variants of the runner:
+drains every batch of the schedule through the C-ABI IPC client, for the two RunOnce variants of the runner:
 
-    LEGION_RUNNER_PIPELINE=0   the reference's loop: enqueue, wait for the batch, post (Server.cu:301-328)
     (default)                  enqueue batch i, then wait for batch i-1 and post it (sampler i || gathers i-1)
-    LEGION_BATCH_GRAPH=1       one recorded hipGraph per (pipe, mode), one stream
-    LEGION_BATCH_GRAPH=2       the same as a fork/join graph (the two-stream op loop as recorded)
-    LEGION_BATCH_GRAPH=3       the sampler side as a graph, the rows gathered by one plain launch on stream 1 behind it
+    LEGION_BATCH_GRAPH=1       the sampler side as a recorded hipGraph, the rows gathered by one plain launch on stream 1 behind it
+(the reference's synchronous loop and the whole-batch graphs lost at every shape: profiles/r01_server_loop.md, r04_graph_trace.md)
 
     python examples/serve_bench.py [--workload products --scale 0.3 --batch 8000 --fanout 25,10 --epochs 3]
 """
@@ -51,7 +49,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8000)
     ap.add_argument("--fanout", default="25,10")
     ap.add_argument("--epochs", type=int, default=20)
-    ap.add_argument("--variants", default="all", help="comma list of: reference loop,pipelined,hipGraph,fork/join graph,graph + gather")
+    ap.add_argument("--variants", default="all", help="comma list of: pipelined,graph + gather")
     ap.add_argument("--full-eval", action="store_true", help="keep the full validation / test sets (512-seed batches)")
     ap.add_argument("--source", default="files", choices=["files", "synth"],
                     help="files: write the dataset in Legion's raw layout and let the server read it (GPUGraphStore.cu:254-325).  synth: the server generates "
@@ -85,11 +83,9 @@ def main():
 
 def serve_variants(a, tmp, meta):
     server = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
-    variants = [("reference loop", {"LEGION_RUNNER_PIPELINE": "0"}), ("pipelined", {}), ("hipGraph", {"LEGION_BATCH_GRAPH": "1"}),
-                ("fork/join graph", {"LEGION_BATCH_GRAPH": "2"}), ("graph + gather", {"LEGION_BATCH_GRAPH": "3"}), ("pipelined", {}),
-                ("graph + gather", {"LEGION_BATCH_GRAPH": "3"})]
+    variants = [("pipelined", {}), ("graph + gather", {"LEGION_BATCH_GRAPH": "1"}), ("pipelined", {}), ("graph + gather", {"LEGION_BATCH_GRAPH": "1"})]
     if a.variants != "all":
-        variants = [v for v in variants[:5] if v[0] in a.variants.split(",")]
+        variants = [v for v in variants[:2] if v[0] in a.variants.split(",")]
     for name, extra in variants:
         ns = "sb%d_%s%s_" % (os.getpid(), name[:3], extra.get("LEGION_BATCH_GRAPH", ""))
         env = dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)

@@ -122,8 +122,8 @@ typedef struct LegionBuildInfo {
     int32_t float_attr_pitch;
 } LegionBuildInfo;
 /* Row pitch (in floats) the library gives the HBM copies it owns (table replicas, cache shards): F when a row is a whole
- * number of 128-byte lines, else F rounded up to 32 floats (F = 100 -> 128: every 400-byte row read then starts on a line)
- * -- unless $LEGION_ROW_PITCH=dense.  The trainer-facing feature buffer stays dense [n, F]. */
+ * number of 128-byte lines, else F rounded up to 32 floats (F = 100 -> 128: every 400-byte row read then starts on a line).
+ * The trainer-facing feature buffer stays dense [n, F]. */
 int32_t legion_row_pitch(int32_t F);
 /* Row pitch of the feature-cache shards: legion_row_pitch(F) when `rows` padded rows fit `feat_budget_bytes` (the feature
  * share of the reference's cache_memory contract, GPUCache.cu:674,727: capacity = budget / (F * 4)), else F (dense);
@@ -145,14 +145,6 @@ void GPUGraphStorage_Finalize(GPUGraphStorage* g);
 /* MI355X-first: copy the whole CSR into the HBM of every local GPU (one replica per physical device); the
  * sampler then reads its own replica instead of the pinned-host table.  Returns bytes per replica (0: nothing done). */
 int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g);
-/* Head tables over the HBM copies of the whole CSR (built by Build() for a device-resident CSR and by ReplicateToDevices()):
- * one 64- or 128-byte entry per node holding its degree and -- when they fit -- its neighbours, so that the sampler reads ONE
- * random line per low-degree source row instead of the indptr pair and the adjacency line (MI355X: HBM capacity traded for
- * random accesses; papers100M shape: 7.1 GB).  $LEGION_HEAD_TABLE = 0 (default) | auto | 16 | 32 (ints per entry).  Same draws,
- * same neighbours: bit-identical output.  An option, not the default: it is worth 1-2 % of the sampler at the papers100M and
- * products shapes and costs 4-9 % at uk-union 3-hop (profiles/r03_sampler.md).  Returns the bytes per device (0: none built). */
-int64_t GPUGraphStorage_BuildHeadTables(GPUGraphStorage* g);
-int32_t* GPUGraphStorage_GetHeadTable(const GPUGraphStorage* g, int32_t dev_id, int32_t* ints_per_entry);
 int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g);
 int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g);
 int32_t* GPUGraphStorage_GetCSRNodeMatrixCPU(const GPUGraphStorage* g);
@@ -292,10 +284,10 @@ float* GPUCache_Float_Feature_Cache(const GPUCache* c, int32_t dev_id);
  * error (LEGION_ERR_EXIT: the server exits non-zero instead of leaving a trainer stalled in ipc_service.initialize()).
  * Shards and fragments are lists of <= $LEGION_SHARD_CHUNK_BYTES (default 1 GiB) chunks and are not affected.
  * The FEATURE hand-off buffer (rows x F x 4 bytes per pipe -- the one that does outgrow the limit, 8.6 GB at the uk-union 3-hop
- * shape) is then built from <= $LEGION_HANDOFF_CHUNK_BYTES (default 1 GiB) physical chunks (HIP virtual memory management),
+ * shape) is then built from <= $LEGION_SHARD_CHUNK_BYTES (default 1 GiB) physical chunks (HIP virtual memory management),
  * exported as POSIX file descriptors over an abstract unix socket and mapped back to back into one virtual range by
  * legion_ipc_client_open, so the trainer still sees one contiguous tensor; its 64-byte handle slot in the shm table carries
- * a descriptor ("LGNVMM01", total, chunk, count) instead of an IPC handle.  $LEGION_HANDOFF_VMM=1 forces that path. */
+ * a descriptor ("LGNVMM01", total, chunk, count) instead of an IPC handle. */
 #define LEGION_IPC_MAX_BYTES_DEFAULT 2145386496ll /* 2^31 - 2 MiB: the largest size verified with the torch-bundled runtime */
 /* HIP-IPC exchange of a clique member's feature shard (64-byte handle); returns 0 on success */
 int GPUCache_ExportFeatureShard(GPUCache* c, int32_t dev_id, void* handle64);
@@ -425,7 +417,7 @@ int IPCEnv_SlabPinned(IPCEnv* e);   /* 1: the slab is page-locked (hipHostRegist
 void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 int IPCEnv_IPCTryWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t timeout_ms); /* 0 = acquired */
-/* Both sides poll the semaphore for $LEGION_HANDOFF_SPIN_US microseconds (default 200; 0 = block at once) before they block on it: a futex
+/* Both sides poll the semaphore for this many microseconds (200) before they block on it: a futex
  * wake-up costs 10-60 us and sits on the depth-2 handshake of every batch (profiles/r05_handoff_spin.md). */
 int IPCEnv_HandoffSpinUs(void);
 void IPCEnv_Finalize(IPCEnv* e);

@@ -105,8 +105,6 @@ _SIGS = {
     "GPUGraphStorage_Build": (None, [vp, vp]),
     "GPUGraphStorage_GraphCache": (None, [vp, vp, i32, i32, i32]),
     "GPUGraphStorage_ReplicateToDevices": (i64, [vp]),
-    "GPUGraphStorage_BuildHeadTables": (i64, [vp]),
-    "GPUGraphStorage_GetHeadTable": (vp, [vp, i32, vp]),
     "GPUNodeStorage_ReplicateToDevices": (i64, [vp]),
     "GPUGraphStorage_Finalize": (None, [vp]),
     "GPUGraphStorage_Delete": (None, [vp]),

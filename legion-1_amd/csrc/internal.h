@@ -44,20 +44,12 @@ struct DeviceGuard {
 // ---- constants --------------------------------------------------------------------------------
 // Position-table entry: (epoch << kPosShift) | value.  epoch = kEpochTop - batch serial: entries of older batches compare GREATER than
 // anything of the running batch (stale without being touched); value = kProvisional | slot idx while claimed in the running hop, else
-// the node's final index in sampled_ids.  Default: u64 entries, 32-bit epoch (never wraps in practice).
-// -DLEGION_POS32 (experiment, profiles/r05_sampler.md): u32 entries -- 7-bit epoch, provisional flag, 24-bit value -- half the table
-// (889 -> 444 MB at the papers100M shape, 19.6 -> 9.8 MB at products), wiped every 126 batches; needs batch x prod(fan-outs) <= 2^24.
-#ifdef LEGION_POS32
-typedef uint32_t pos_t;
-constexpr int kPosShift = 25;
-constexpr uint32_t kProvisional = 1u << 24, kPosValueMask = 0x00FFFFFFu;
-constexpr uint32_t kEpochTop = 127u, kSerialLimit = 127u;
-#else
+// the node's final index in sampled_ids.  u64 entries, 32-bit epoch (never wraps in practice).  (A u32 entry -- 7-bit epoch, flag, 24-bit
+// value, wiped every 126 batches -- was bit-identical and lost at two of three shapes: profiles/r05_sampler.md, r06_removed_experiments.patch.)
 typedef unsigned long long pos_t;
 constexpr int kPosShift = 32;
 constexpr uint32_t kProvisional = 0x80000000u, kPosValueMask = 0x7FFFFFFFu;
 constexpr uint32_t kEpochTop = 0xFFFFFFFFu, kSerialLimit = 0xFFFFFFF0u;
-#endif
 __host__ __device__ inline pos_t pos_entry(uint32_t epoch, uint32_t value) { return ((pos_t)epoch << kPosShift) | (pos_t)value; }
 #ifndef LEGION_KTILE
 #define LEGION_KTILE 1024
@@ -114,12 +106,6 @@ struct CsrTables {                 // GPU_Memory_Graph_Storage.cu:45-133: the wh
     int32_t partition_count;
     const int8_t* topo_owner;      // int8[V]  owner logical GPU or -1 (edge_index_map), may be null
     const int32_t* topo_row;       // int32[V] row in the owner's fragment (edge_offset_map)
-    // Head table (HBM copies of the whole CSR only; may be null): one 2^head_shift-int entry per node, aligned to its size:
-    //   [0] = degree (the int32 the sampler uses);  degree <= 2^head_shift - 1: [1 ..] = the neighbours, i.e. ONE random line
-    //   holds everything a low-degree row needs (today: indptr pair + adjacency line = two dependent random accesses);
-    //   larger rows: [1], [2] = low / high word of the row's first edge offset, the neighbours stay in `indices`.
-    const int32_t* head;
-    int32_t head_shift;            // 4: 64-byte entries (<= 15 neighbours inline), 5: 128-byte entries (<= 31)
 };
 
 struct BatchCtl {                  // device-resident batch cursor (see k_seed)
@@ -226,7 +212,6 @@ void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t K
 void launch_chunk_ends(hipStream_t s, const int64_t* frag_indptr, int32_t capacity, int32_t edge_shift, int32_t nch, int64_t* ends);
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr);
 void launch_topo_transactions(hipStream_t s, const int32_t* order, const uint64_t* hot, uint64_t* out, int32_t V, const int64_t* indptr);
-void launch_build_head(hipStream_t s, const int64_t* indptr, const int32_t* indices, int32_t V, int32_t head_shift, int32_t* head);
 void sort_by_hotness_desc(hipStream_t s, unsigned long long* keys, int32_t* ids, int32_t n);
 void inclusive_scan_u64(hipStream_t s, const uint64_t* in, uint64_t* out, int32_t n);
 void inclusive_scan_i64(hipStream_t s, const int64_t* in, int64_t* out, int32_t n);
@@ -289,8 +274,6 @@ struct GPUGraphStorage {
     // HBM replicas of the whole CSR, one per logical GPU that has one (GPUGraphStorage_ReplicateToDevices)
     std::vector<int64_t*> replica_indptr;
     std::vector<int32_t*> replica_indices;
-    std::vector<int32_t*> head;              // per logical GPU: head table over its HBM copy of the whole CSR (see CsrTables), or null
-    int32_t head_shift = 4;
     int32_t csr_location = LEGION_LOC_HOST_PINNED;
     bool owns_csr = false;
     // CSR fragment of one logical GPU (device memory on that GPU's physical device).  Both arrays are lists of

@@ -68,13 +68,9 @@ static bool no_device()
 
 // Waiting for the other side of the hand-off: poll the semaphore for a bounded time before blocking on it.  A blocked waiter is woken
 // through the kernel (futex) -- 10-60 us on an idle core -- and that latency sits on the depth-2 handshake of every batch: the server may only
-// refill a pipe after the trainer has handed it back.  $LEGION_HANDOFF_SPIN_US (default 200; 0 = block at once, rounds 1-4): how long a
-// waiter polls first.  A trainer that is the bottleneck costs the server at most that much polling per batch, then it sleeps as before.
-static int handoff_spin_us()
-{
-    static const int v = [] { const char* e = getenv("LEGION_HANDOFF_SPIN_US"); const int x = e ? atoi(e) : 200; return x < 0 ? 0 : (x > 100000 ? 100000 : x); }();
-    return v;
-}
+// refill a pipe after the trainer has handed it back.  A waiter polls for 200 us first (profiles/r05_handoff_spin.log: 0 / 50 / 200 / 1000 us
+// measured, 200 kept).  A trainer that is the bottleneck costs the server at most that much polling per batch, then it sleeps as before.
+static int handoff_spin_us() { return 200; }
 static inline int64_t mono_ns()
 {
     timespec ts;
@@ -238,7 +234,7 @@ static VmmRegion* vmm_create(int logical_dev, int pipe, size_t bytes)
         LEGION_ARG_ERROR("hand-off buffer above the HIP-IPC limit: this runtime has no virtual memory management");
         return nullptr;
     }
-    const char* e = getenv("LEGION_HANDOFF_CHUNK_BYTES");
+    const char* e = getenv("LEGION_SHARD_CHUNK_BYTES");     // one chunk size for everything that crosses a process boundary in pieces
     size_t chunk = e && atoll(e) > 0 ? (size_t)atoll(e) : ((size_t)1 << 30);
     chunk = std::max(gran, chunk / gran * gran);
     VmmRegion* r = new VmmRegion();
@@ -287,8 +283,7 @@ static hipError_t vmm_import_fd(hipMemGenericAllocationHandle_t* h, int fd)
     if (by_pointer < 0) {
         int v = 0;
         if (hipRuntimeGetVersion(&v) != hipSuccess) { (void)hipGetLastError(); v = 0; }
-        const char* e = getenv("LEGION_VMM_FD_BY_POINTER");          // override for a runtime that reports an unexpected version
-        by_pointer = e ? (atoi(e) != 0) : (v < 70100000);
+        by_pointer = v < 70100000;
     }
     static thread_local int fd_cell;
     fd_cell = fd;
@@ -344,9 +339,8 @@ IPCEnv* NewIPCEnv(int32_t device_count)
         return nullptr;
     }
     log_out() << "Shared Memory Opened\n";
-    // $LEGION_IPC_ATTACH=1: another server process of this job already created the slab
-    const char* attach = getenv("LEGION_IPC_ATTACH");
-    if (!(attach && attach[0] == '1')) { memset((void*)e->shm, 0, sizeof(shmStruct)); memset((void*)e->ext, 0, sizeof(shmExt)); }
+    memset((void*)e->shm, 0, sizeof(shmStruct));
+    memset((void*)e->ext, 0, sizeof(shmExt));
     e->device_count = device_count;
     auto rs = [&](std::vector<std::vector<void*>>& v) { v.assign(device_count, {}); };
     rs(e->ids); rs(e->float_features); rs(e->labels); rs(e->agg_src); rs(e->agg_dst); rs(e->node_counter); rs(e->edge_counter);
@@ -461,8 +455,7 @@ void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_
     if (no_device()) return;
     DeviceGuard guard(device_id);
     const size_t bytes = (size_t)num_ids * feature_dim * sizeof(float);
-    const char* force = getenv("LEGION_HANDOFF_VMM");
-    const bool vmm = (int64_t)bytes > ipc_max_bytes() || (force && force[0] == '1');
+    const bool vmm = (int64_t)bytes > ipc_max_bytes();
     for (int32_t i = 0; i < pipeline_depth; i++) {
         void* p = nullptr;
         if (vmm) {   // too large for one IPC handle under the PyTorch runtime: chunks + one contiguous mapping on both sides

@@ -219,13 +219,6 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
                     ix = a.csr.frag_indices[owner * a.csr.ix_nch + (int32_t)(start >> a.csr.edge_shift)];
                     rowp = ix + (start & ((1ll << a.csr.edge_shift) - 1));
                     deg = (int32_t)(ip[1] - start); // int32 truncation as in Kernels.cu:393,396
-                } else if (!PRESC && a.csr.head) {
-                    // head table of the whole-CSR copy: degree and -- for rows that fit -- the neighbours themselves in ONE line
-                    const int32_t* hp = a.csr.head + ((int64_t)src << a.csr.head_shift);
-                    const int4 h4 = *reinterpret_cast<const int4*>(hp);        // entries are 64 / 128-byte aligned: one 16-byte load
-                    deg = h4.x;
-                    if (deg < (1 << a.csr.head_shift)) rowp = hp + 1;
-                    else rowp = ix + (int64_t)(((uint64_t)(uint32_t)h4.z << 32) | (uint32_t)h4.y);
                 } else {
                     const int64_t start = ip[0];
                     rowp = ix + start;
@@ -330,9 +323,8 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 // itself (round 1 needed a fourth launch per hop, k_resolve, for that).
 constexpr int32_t kWinBase = 0x40000000;   // loser states are -2 - slot with slot < 2^30; winner ranks sit below them
 
-// cached gather: 0 = lookup pass (k_row_ptrs), U > 0 = k_gather_lookup<U>.  Same box, papers100M shape, 25 % of the rows cached: pass 416-423 us,
-// U = 1: 455, U = 2: 412-414, U = 4: 418 (profiles/r04_cached_gather.md) -- the probes themselves (1.94 M random 4-byte reads of a 444 MB map) bound it
-constexpr int kGatherLookupDefault = 2;
+// (cached gather, same box, papers100M shape, 25 % of the rows cached: lookup pass k_row_ptrs + k_gather 416-423 us; k_gather_lookup<U> with U = 1: 455,
+// U = 2: 412-414, U = 4: 418 (profiles/r04_cached_gather.md) -- the probes themselves (1.94 M random 4-byte reads of a 444 MB map) bound it: U = 2 is built)
 __device__ inline int32_t enc_win(int32_t r) { return -2 - (kWinBase + r); }
 __device__ inline bool is_win(int32_t v) { return v <= -2 - kWinBase; }
 __device__ inline int32_t win_rank(int32_t v) { return -2 - v - kWinBase; }
@@ -486,13 +478,8 @@ struct WriteArgs {
 // k_mark the offsets are below the buffers' capacity by construction (num_ids = the sum of the static per-hop bounds); an experiment
 // that skips or breaks the prefix build writes through uninitialised offsets -- round 4's timing-only variant did, and hung its run
 // (profiles/r04_sampler.md).  The bound check makes such a variant drop the store instead of running away; it is one unsigned compare
-// per store in a kernel that waits for memory (measured: profiles/r05_sampler.md), so it stays on in the shipped build.
-// -DLEGION_UNBOUNDED_STORES removes it (the A/B that measured it).
-#ifdef LEGION_UNBOUNDED_STORES
-#define LEGION_STORE_OK(i, cap) true
-#else
+// per store in a kernel that waits for memory (+0.3-0.6 us per launch: profiles/r05_sampler.md, r05_ab_bounded_stores.log).
 #define LEGION_STORE_OK(i, cap) ((uint32_t)(i) < (uint32_t)(cap))
-#endif
 
 __global__ __launch_bounds__(kBlock) void k_write(WriteArgs a)
 {
@@ -676,7 +663,6 @@ struct GatherKArgs {
     GatherArgs g;
     FastDiv div_c;   // / chunks-per-row
     FastDiv div_cap; // / cache_capacity
-    int32_t lpr_shift; // >= 0: every row owns 2^lpr_shift lanes (row-aligned layout, see k_gather); < 0: dense q / C
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -727,10 +713,9 @@ __global__ __launch_bounds__(kBlock) void k_row_ptrs(GatherKArgs a)
     if (g.hit_stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(g.hit_stats + 1, rows);
 }
 
-// Row layout of the flat work space: q -> (row, 16-byte chunk).  Dense (lpr_shift < 0): q / C, q % C -- a wave covers
-// 64 consecutive chunks whatever the row length.  Row-aligned (lpr_shift >= 0, chosen by the launcher when C is not a
-// divisor of 64, e.g. F = 100: C = 25): every row owns 2^lpr_shift lanes, the lanes >= C idle, so a wave always holds
-// whole rows and with a 128-byte-aligned source pitch every row read starts on a line.
+// Row layout of the flat work space: q -> (row, 16-byte chunk) = (q / C, q % C) -- a wave covers 64 consecutive chunks whatever
+// the row length.  (A row-aligned layout -- 2^k lanes per row, the lanes >= C idle -- lost 5 % at F = 100:
+// profiles/r03_other_shapes.md; kept as profiles/r06_removed_experiments.patch.)
 template <typename VT, int UNROLL, int NT>
 __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
 {
@@ -739,8 +724,7 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
     const int32_t off = g.off_idx < 0 ? 0 : g.nc[g.off_idx];
     const int32_t rows = g.nc[g.size_idx];
     const int32_t C = g.F / VEC;
-    const int32_t lpr = a.lpr_shift;
-    const int64_t total = lpr >= 0 ? ((int64_t)rows << lpr) : (int64_t)rows * C;
+    const int64_t total = (int64_t)rows * C;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t pitch = g.table_pitch > 0 ? g.table_pitch : g.F;   // floats between two rows of the backing table
     if (g.rows_seen && blockIdx.x == 0 && threadIdx.x == 0) *g.rows_seen = rows; // launch-size feedback for later batches
@@ -754,15 +738,8 @@ __global__ __launch_bounds__(kBlock) void k_gather(GatherKArgs a)
             src[u] = nullptr;
             dsti[u] = 0;
             if (q < total) {
-                uint32_t r, ch;
-                if (lpr >= 0) {
-                    r = (uint32_t)(q >> lpr);
-                    ch = (uint32_t)q & ((1u << lpr) - 1u);
-                    if ((int32_t)ch >= C) continue;
-                } else {
-                    r = fdiv((uint32_t)q, a.div_c); // rows*C < 2^31 is checked by the launcher
-                    ch = (uint32_t)q - r * (uint32_t)C;
-                }
+                const uint32_t r = fdiv((uint32_t)q, a.div_c); // rows*C < 2^31 is checked by the launcher
+                const uint32_t ch = (uint32_t)q - r * (uint32_t)C;
                 if (g.dst_rows > 0 && off + (int32_t)r >= g.dst_rows) continue; // never write past the buffer
                 dsti[u] = ((int64_t)(off + (int32_t)r) * g.F) / VEC + ch;
                 if (g.row_ptr) { // resolved by k_row_ptrs
@@ -1077,24 +1054,6 @@ __global__ void k_chunk_ends(const int64_t* frag_indptr, int32_t capacity, int32
     }
     ends[q] = frag_indptr[lo];
 }
-// Head table over a device-resident CSR (see CsrTables::head): W = 2^shift ints per node, one lane per int
-__global__ void k_build_head(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, int32_t V, int32_t shift,
-                             int32_t* __restrict__ head)
-{
-    const int64_t n = (int64_t)V << shift;
-    const int32_t W = 1 << shift;
-    for (int64_t i = threadIdx.x + (int64_t)blockDim.x * blockIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t v = (int32_t)(i >> shift), c = (int32_t)(i & (W - 1));
-        const int64_t start = indptr[v];
-        const int32_t deg = (int32_t)(indptr[v + 1] - start);      // the sampler's int32 degree (Kernels.cu:393,396)
-        int32_t out = 0;
-        if (c == 0) out = deg;
-        else if (deg >= 0 && deg < W) out = (c <= deg) ? indices[start + c - 1] : 0;
-        else if (c == 1) out = (int32_t)(uint32_t)(start & 0xFFFFFFFFll);
-        else if (c == 2) out = (int32_t)(uint32_t)((uint64_t)start >> 32);
-        head[i] = out;
-    }
-}
 // GetEdgeMem (GPUCache.cu:35-41)
 __global__ void k_edge_mem(const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)
 {
@@ -1202,8 +1161,8 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     const int max_tiles = (slots_bound + kTile - 1) / kTile;
     // Workgroups per CU of the persistent tile loops.  The memory system is saturated by the scattered probes long before the CUs
     // are full: 4 workgroups (16 waves) per CU beat 8 by 2-4 % on hop 3 at every shape and tie on the small hops; 3 lose on hop 2
-    // (same-box sweep, profiles/r04_sampler.md).  $LEGION_SAMPLE_WG_PER_CU overrides (1..8).
-    static const int wg_per_cu = [] { const char* e = getenv("LEGION_SAMPLE_WG_PER_CU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 8 ? v : 4; }();
+    // (same-box sweep, profiles/r04_sampler.md).
+    constexpr int wg_per_cu = 4;
     const int grid = std::min(grid_for(max_tiles, 1, wg_per_cu), kMaxChunks);   // one chunk of tiles per k_mark workgroup (see k_mark)
     if (!b.aux_prepared) { // the previous launch prepared the slot states for another fan-out (or there was none)
         k_fill_aux<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.nc, count, b.aux, b.aux_cap);
@@ -1221,9 +1180,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     a.fdiv = FastDiv((uint32_t)count);
     a.count = count; a.op_id = op_id;
     a.window = std::min(count - 1, 8);
-    // hop 1 goes straight to the atomic (see k_sample); $LEGION_PREFILTER_FROM_HOP moves that boundary (experiment knob, profiles/r04_sampler.md)
-    static const int prefilter_from_hop = [] { const char* e = getenv("LEGION_PREFILTER_FROM_HOP"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 9 ? v : 2; }();
-    a.prefilter_from_op = 2 * prefilter_from_hop;
+    a.prefilter_from_op = 4;   // hop 1 goes straight to the atomic (see k_sample; moving the boundary lost: profiles/r04_sampler.md)
     const bool part = csr.topo_owner != nullptr;
     if (is_presc) k_sample<true, false><<<grid, kBlock, 0, s>>>(a);
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
@@ -1268,17 +1225,7 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // cache chunks are hipMalloc'ed (256-byte aligned) and hold whole rows: F % 4 == 0 keeps rows 16-byte aligned
     bool vec4 = (g.F % 4 == 0) && (((uintptr_t)g.table | (uintptr_t)g.dst) % 16 == 0);
     const int C = vec4 ? g.F / 4 : g.F;
-    // row-aligned lane layout (see k_gather): measured at F = 100 (profiles/r03_other_shapes.md) it is SLOWER than the dense
-    // q / C layout (146.8 vs 137.2 us at the products {25,10} shape: the idle lanes cost more issue slots than the aligned
-    // starts save), so it is only used on request ($LEGION_GATHER_ROW_LANES=1)
-    const char* lpr_env = getenv("LEGION_GATHER_ROW_LANES");
-    a.lpr_shift = -1;
-    int lanes = C;
-    if (vec4 && C < 64 && (64 % C) != 0 && lpr_env && atoi(lpr_env) == 1) {
-        int sh = 0;
-        while ((1 << sh) < C) sh++;
-        a.lpr_shift = sh; lanes = 1 << sh;
-    }
+    const int lanes = C;
     if ((int64_t)rows_bound * lanes >= (1ll << 31)) { LEGION_ARG_ERROR("get_feature_kernel: rows*F exceeds 2^31 work items"); return; }
     a.div_c = FastDiv((uint32_t)C);
     // Tuned on MI355X (profiles/r01_gather_sweep.md): non-temporal loads and stores (rows are read once and
@@ -1288,17 +1235,13 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     // bound is typically filled 15-60 %, so the grid is sized from the row count an earlier launch of this kind
     // reported (rows_seen, no host round trip), + 25 %; without a report: the bound, at most 512 workgroups per CU.
     int grid;
-    // cached configurations: FindFeat + source selection.  $LEGION_GATHER_LOOKUP = pass (k_row_ptrs in front of the gather) |
-    // fused[1|2|4] (k_gather_lookup: one probe per row and wave inside the gather, U work items per lane).  A batch whose hit rate
-    // is sampled (every 500th) takes the pass: it counts every row exactly once.
-    int fused_u = 0;
+    // cached configurations: FindFeat + source selection run inside the gather (k_gather_lookup: one probe per row and wave, two work
+    // items per lane).  A batch whose hit rate is sampled (every 500th) and a backing table in host memory take the lookup pass
+    // (k_row_ptrs in front of k_gather): it counts every row exactly once / keeps the PCIe rows at full width.
+    bool fused = false;
     if (g.row_ptr && !g.row_ptr_ready) {
-        const char* e = getenv("LEGION_GATHER_LOOKUP");      // read per launch (a getenv is ~50 ns): tests switch it inside one process
-        int lookup_mode = kGatherLookupDefault;
-        if (e && !strncmp(e, "pass", 4)) lookup_mode = 0;
-        else if (e && !strncmp(e, "fused", 5)) lookup_mode = e[5] ? atoi(e + 5) : 2;
-        fused_u = (lookup_mode > 0 && !g.hit_stats && !g.table_on_host && a.lpr_shift < 0) ? lookup_mode : 0;
-        if (!fused_u) {
+        fused = !g.hit_stats && !g.table_on_host;
+        if (!fused) {
             const int64_t est_rows = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
             k_row_ptrs<<<grid_for(est_rows, kBlock * 4, 64), kBlock, 0, s>>>(a);
             HIP_CHECK_LAST();
@@ -1312,11 +1255,7 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     } else {
         grid = grid_for((int64_t)rows_bound * lanes, kBlock, 512);
     }
-    if (fused_u) {
-        if (fused_u >= 4) { if (vec4) k_gather_lookup<v4f, 4><<<grid, kBlock, 0, s>>>(a); else k_gather_lookup<float, 4><<<grid, kBlock, 0, s>>>(a); }
-        else if (fused_u >= 2) { if (vec4) k_gather_lookup<v4f, 2><<<grid, kBlock, 0, s>>>(a); else k_gather_lookup<float, 2><<<grid, kBlock, 0, s>>>(a); }
-        else { if (vec4) k_gather_lookup<v4f, 1><<<grid, kBlock, 0, s>>>(a); else k_gather_lookup<float, 1><<<grid, kBlock, 0, s>>>(a); }
-    }
+    if (fused) { if (vec4) k_gather_lookup<v4f, 2><<<grid, kBlock, 0, s>>>(a); else k_gather_lookup<float, 2><<<grid, kBlock, 0, s>>>(a); }
     else if (vec4) k_gather<v4f, 1, 2><<<grid, kBlock, 0, s>>>(a);
     else k_gather<float, 1, 2><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
@@ -1444,12 +1383,6 @@ void launch_chunk_ends(hipStream_t s, const int64_t* frag_indptr, int32_t capaci
 {
     if (nch <= 1) return;
     k_chunk_ends<<<(nch + 63) / 64, 64, 0, s>>>(frag_indptr, capacity, edge_shift, nch, ends);
-    HIP_CHECK_LAST();
-}
-void launch_build_head(hipStream_t s, const int64_t* indptr, const int32_t* indices, int32_t V, int32_t head_shift, int32_t* head)
-{
-    if (V <= 0) return;
-    k_build_head<<<grid_for((int64_t)V << head_shift, 256, 64), 256, 0, s>>>(indptr, indices, V, head_shift, head);
     HIP_CHECK_LAST();
 }
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)

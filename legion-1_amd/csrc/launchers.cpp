@@ -114,8 +114,6 @@ void GPU_Random_Sampling(void* strm_hdl, GPUGraphStorage* graph, GPUCache* cache
     csr.ip_nch = csr.ix_nch = 1; csr.row_shift = graph->row_shift; csr.edge_shift = graph->edge_shift;
     csr.topo_owner = nullptr;
     csr.topo_row = nullptr;
-    csr.head = graph->head[dev];          // null: indptr + adjacency (pinned host tables, partitioned fragments, $LEGION_HEAD_TABLE=0)
-    csr.head_shift = graph->head_shift;
     SamplerBuffers b;
     const int q = p->current_pipe;
     b.sampled_ids = p->sampled_ids[q]; b.agg_src_ids = p->agg_src_ids; b.agg_src_off = p->agg_src_off[q];

@@ -30,13 +30,15 @@ struct Runner {
     std::vector<Operator*> op_factory;
     std::vector<OpParams*> op_params;
     int32_t feature_rows = 0;
-    // $LEGION_BATCH_GRAPH=1: RunOnce replays one recorded hipGraph per (pipe, mode) instead of launching the ops
+    // $LEGION_BATCH_GRAPH=1: the sampler side of a batch (BatchGen, samplers, planner) is replayed as ONE recorded hipGraph per (pipe, mode)
+    // on stream 0 and the rows are gathered by one plain launch on stream 1 behind it -- for launch-bound hosts / small batches
+    // (-8 % / -5 % per batch at 0.3 x products, a tie at the BASELINE shapes: profiles/r04_graph_trace.md).  The whole batch as one graph
+    // (one stream: loses the gather / sampler overlap; fork / join: 38-42 us of idle per batch on this runtime) lost to it at every shape and
+    // is no longer a runner mode (profiles/r06_removed_experiments.patch); GPUMemoryPool_Begin/EndBatchCapture still record any op list.
     bool use_graph = false;
-    int graph_mode = 0;             // $LEGION_BATCH_GRAPH: 1 one-stream graph, 2 fork/join graph, 3 sampler graph + gather launched on stream 1
-    // Software pipelining of RunOnce (default; $LEGION_RUNNER_PIPELINE=0 = the reference's synchronous loop): the
-    // host enqueues batch i and only then waits for batch i-1 and posts its pipe, so the sampler of batch i
-    // (stream 0) overlaps the gathers of batch i-1 (stream 1) on the GPU.
-    bool pipelined = true;
+    // RunOnce is software-pipelined: the host enqueues batch i and only then waits for batch i-1 and posts its pipe, so the sampler of
+    // batch i (stream 0) overlaps the gathers of batch i-1 (stream 1) on the GPU.  (The reference's synchronous loop, Server.cu:301-328,
+    // waits for batch i before it looks at batch i+1.)
     // $LEGION_RUNNER_GATHER = auto (default) | level | all.  level: one FeatureExtractor op per level on stream 1 behind each hop (the reference's
     // op list, Server.cu:198-207).  all: ONE gather over all rows behind the last hop (get_feature_kernel_all).  Same bytes in the same buffer.
     // Which is faster depends on the shape (profiles/r05_runner_gather.md, served batches, same box): when the gather outweighs the sampler the
@@ -96,8 +98,7 @@ void Runner_Initialize(Runner* r, RunnerParams* params)
     r->op_factory[r->op_num - 1] = NewCacheUpdater(r->op_num - 1);
 
     r->pipeline_depth = LEGION_PIPELINE_DEPTH;
-    { const char* e = getenv("LEGION_BATCH_GRAPH"); r->graph_mode = e ? atoi(e) : 0; r->use_graph = r->graph_mode != 0; }
-    { const char* e = getenv("LEGION_RUNNER_PIPELINE"); r->pipelined = !(e && atoi(e) == 0); }
+    { const char* e = getenv("LEGION_BATCH_GRAPH"); r->use_graph = e && atoi(e) != 0; }
     { const char* e = getenv("LEGION_RUNNER_GATHER"); r->gather_all = e && strcmp(e, "all") == 0; r->gather_auto = !e || strcmp(e, "auto") == 0; }
     for (auto& ev : r->done_ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     const int total_num_nodes = GPUNodeStorage_TotalNodeNum(noder);
@@ -217,7 +218,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     if (r->pending) {
         // Pipelined loop: batch i-1 is in flight.  Wait for the trainer to free this pipe, but hand batch i-1 over
         // the moment it is complete -- a trainer that is the bottleneck must not wait for our next enqueue.
-        // Poll first ($LEGION_HANDOFF_SPIN_US, default 200 us): the trainer usually frees the pipe within tens of microseconds of the post at the
+        // Poll first (IPCEnv_HandoffSpinUs, 200 us): the trainer usually frees the pipe within tens of microseconds of the post at the
         // end of the previous RunOnce, and a sleep_for(10 us) really sleeps 60+ us (timer slack) -- on the critical chain of every batch
         // (gather i-1 done -> post -> trainer -> pipe free -> sampler i+1 may start).  After the polling budget: sleep between looks, as before.
         const auto t_wait = std::chrono::steady_clock::now();
@@ -274,24 +275,14 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         LegionBatchGraph*& g = r->graphs[r->current_pipe][r->mode];
         if (!g) { // record this (pipe, mode) once
             if (GPUMemoryPool_BeginBatchCapture(r->memorypool, r->streams[0]) == 0) {
-                if (r->graph_mode == 2) {
-                    // the two-stream op loop as recorded -- stream 1 joins the capture through the op events and is joined back
-                    // before the capture ends (profiles/r04_graph_trace.md has the comparison)
-                    run_ops();
-                    HIP_CHECK(hipEventRecord(r->events[r->op_num - 1], r->streams[1]));
-                    HIP_CHECK(hipStreamWaitEvent(r->streams[0], r->events[r->op_num - 1], 0));
-                } else {
-                    // recorded on ONE stream.  Mode 3 records the sampler side only (BatchGen, samplers, planner: the even ops);
-                    // the rows are gathered by one plain launch on stream 1 behind the graph, so the gather of batch i overlaps
-                    // the recorded sampler of batch i + 1 (the other pipe) -- what a single graph per batch cannot do
-                    for (int i = 0; i < r->op_num; i++) {
-                        if (r->graph_mode == 3 && (i & 1)) continue;
-                        OpParams op = *r->op_params[i];
-                        op.stream = r->streams[0];
-                        op.event = nullptr;
-                        op.is_presc = 0;
-                        Operator_run(r->op_factory[i], &op);
-                    }
+                // the sampler side only (BatchGen, samplers, planner: the even ops), on ONE stream; the rows are gathered by one plain
+                // launch on stream 1 behind the graph, so the gather of batch i overlaps the recorded sampler of batch i + 1 (the other pipe)
+                for (int i = 0; i < r->op_num; i += 2) {
+                    OpParams op = *r->op_params[i];
+                    op.stream = r->streams[0];
+                    op.event = nullptr;
+                    op.is_presc = 0;
+                    Operator_run(r->op_factory[i], &op);
                 }
                 g = GPUMemoryPool_EndBatchCapture(r->memorypool, r->streams[0]);
             }
@@ -303,25 +294,18 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
             }
         }
         LegionBatchGraph_Launch(g, r->streams[0], IPCEnv_GetLocalBatchId(env, batch_id));
-        hipStream_t last = r->streams[0];
-        if (r->graph_mode == 3) {
-            HIP_CHECK(hipEventRecord(r->events[0], r->streams[0]));
-            HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[0], 0));
-            OpParams* fp = r->op_params[1];
-            get_feature_kernel_all(r->streams[1], (GPUCache*)fp->cache, (GPUNodeStorage*)fp->noder, r->memorypool, fp->device_id, fp->in_memory);
-            Operator_run(r->op_factory[r->op_num - 1], r->op_params[r->op_num - 1]);   // Updater, stream 1
-            last = r->streams[1];
-        }
-        IPCEnv_MirrorCounters(env, r->local_dev_id, r->current_pipe, last);   // behind every kernel of the batch (the graph / the gather)
-        if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], last));
-        else HIP_CHECK(hipStreamSynchronize(last));
+        HIP_CHECK(hipEventRecord(r->events[0], r->streams[0]));
+        HIP_CHECK(hipStreamWaitEvent(r->streams[1], r->events[0], 0));
+        OpParams* fp = r->op_params[1];
+        get_feature_kernel_all(r->streams[1], (GPUCache*)fp->cache, (GPUNodeStorage*)fp->noder, r->memorypool, fp->device_id, fp->in_memory);
+        Operator_run(r->op_factory[r->op_num - 1], r->op_params[r->op_num - 1]);   // Updater, stream 1
     } else {
         run_ops();
-        // the updater (last op, stream 1) is ordered behind every op of the batch through the op events
-        IPCEnv_MirrorCounters(env, r->local_dev_id, r->current_pipe, r->streams[1]);
-        if (r->pipelined) HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[1]));
-        else HIP_CHECK(hipStreamSynchronize(r->streams[1])); // reference: spin on cudaEventQuery of the updater's event (Server.cu:318-324)
     }
+    // the last op of the batch (updater / gather, stream 1) is ordered behind every other op through the op events; the reference spins on
+    // cudaEventQuery of the updater's event here (Server.cu:318-324) -- this loop hands the batch over one RunOnce later (see `pending`)
+    IPCEnv_MirrorCounters(env, r->local_dev_id, r->current_pipe, r->streams[1]);
+    HIP_CHECK(hipEventRecord(r->done_ev[r->current_pipe], r->streams[1]));
     if (error_pending()) {
         // an operator refused its arguments (sticky error): the buffers of this pipe hold stale data.  Never hand
         // them to a trainer -- the reference's error behaviour is exit(EXIT_FAILURE) (Kernels.cuh:14-22).
@@ -330,18 +314,12 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         post_poisoned();
         return;
     }
-    if (r->pipelined) {
-        if (r->pending) { // batch i is queued: now hand batch i-1 to its trainer
-            HIP_CHECK(hipEventSynchronize(r->done_ev[r->pending_pipe]));
-            IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
-        }
-        r->pending = true;
-        r->pending_pipe = r->current_pipe;
-        r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
-        GPUMemoryPool_SetCurrentPipe(r->memorypool, r->current_pipe);
-        return;
+    if (r->pending) { // batch i is queued: now hand batch i-1 to its trainer
+        HIP_CHECK(hipEventSynchronize(r->done_ev[r->pending_pipe]));
+        IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
     }
-    IPCEnv_IPCPost(env, r->local_dev_id, r->current_pipe);
+    r->pending = true;
+    r->pending_pipe = r->current_pipe;
     r->current_pipe = (r->current_pipe + 1) % r->pipeline_depth;
     GPUMemoryPool_SetCurrentPipe(r->memorypool, r->current_pipe);
 }

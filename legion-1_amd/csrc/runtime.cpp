@@ -97,8 +97,7 @@ extern "C" {
 const char* legion_version(void) { return "legion-amd 0.1.0 (gfx950)"; }
 int32_t legion_row_pitch(int32_t F)
 {
-    const char* e = getenv("LEGION_ROW_PITCH");
-    if (F <= 0 || (e && strcmp(e, "dense") == 0) || (F * 4) % 128 == 0) return F;
+    if (F <= 0 || (F * 4) % 128 == 0) return F;
     return (F + 31) / 32 * 32;
 }
 void legion_set_error_mode(int mode) { g_error_mode = mode; }

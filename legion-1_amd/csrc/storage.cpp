@@ -100,7 +100,6 @@ void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info)
     g->frag.assign(P, GPUGraphStorage::Fragment());
     g->replica_indptr.assign(P, nullptr);
     g->replica_indices.assign(P, nullptr);
-    g->head.assign(P, nullptr);
     g->view.assign(P, std::vector<bool>(P, false));
     g->d_frag_tab.assign(P, nullptr);
     // chunk geometry of the fragments: powers of two that fit $LEGION_SHARD_CHUNK_BYTES (default 1 GiB)
@@ -109,47 +108,6 @@ void GPUGraphStorage_Build(GPUGraphStorage* g, const LegionBuildInfo* info)
     g->row_shift = 4; g->edge_shift = 4;
     while (g->row_shift < 30 && (2ll << g->row_shift) * (int64_t)sizeof(int64_t) <= chunk_bytes) g->row_shift++;
     while (g->edge_shift < 30 && (2ll << g->edge_shift) * (int64_t)sizeof(int32_t) <= chunk_bytes) g->edge_shift++;
-    if (g->csr_location == LEGION_LOC_DEVICE) GPUGraphStorage_BuildHeadTables(g);   // the caller's CSR already is HBM resident
-}
-
-// Head tables (CsrTables::head) over the HBM copies of the whole CSR: one per distinct physical device among the local logical
-// GPUs.  $LEGION_HEAD_TABLE = 0 (default: off) | auto (64-byte entries up to a mean degree of 24, else 128-byte; skipped when it
-// would not leave 20 % of the free HBM) | 16 | 32 (ints per entry).  Returns the bytes allocated per device (0: none).
-// Off by default: measured on MI355X (profiles/r03_sampler.md) it buys 1 % of the sampler at the papers100M shape and 2.4 % at
-// products 3-hop for 7 GB / 0.3 GB of HBM, and costs 4-9 % at uk-union 3-hop (128-byte entries) -- the sampler is not bound by
-// the number of row accesses.
-int64_t GPUGraphStorage_BuildHeadTables(GPUGraphStorage* g)
-{
-    if (!g || g->node_num <= 0) return 0;
-    const char* e = getenv("LEGION_HEAD_TABLE");
-    const std::string mode = e ? e : "0";
-    if (mode == "0" || mode == "off") return 0;
-    int shift = (g->edge_num > 24ll * g->node_num) ? 5 : 4;
-    if (mode == "16") shift = 4;
-    else if (mode == "32") shift = 5;
-    g->head_shift = shift;
-    const size_t bytes = ((size_t)g->node_num << shift) * sizeof(int32_t);
-    std::vector<std::pair<int, int32_t*>> per_phys;
-    for (int p = 0; p < g->partition_count; p++) {
-        if (is_remote_device(p) || g->head[p]) continue;
-        const int64_t* ip = g->replica_indptr[p] ? g->replica_indptr[p] : (g->csr_location == LEGION_LOC_DEVICE ? g->csr_node_index_cpu : nullptr);
-        const int32_t* ix = g->replica_indices[p] ? g->replica_indices[p] : (g->csr_location == LEGION_LOC_DEVICE ? g->csr_dst_node_ids_cpu : nullptr);
-        if (!ip || !ix) continue;                    // this GPU samples from the pinned host table: no head table
-        const int phys = physical_device(p);
-        int32_t* have = nullptr;
-        for (auto& q : per_phys) if (q.first == phys) have = q.second;
-        if (!have) {
-            DeviceGuard guard(p);
-            size_t free_b = 0, total_b = 0;
-            if (mode == "auto" && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)bytes > 0.8 * (double)free_b)) { (void)hipGetLastError(); continue; }
-            if (hipMalloc(&have, bytes) != hipSuccess) { (void)hipGetLastError(); have = nullptr; continue; }
-            launch_build_head(nullptr, ip, ix, g->node_num, shift, have);
-            HIP_CHECK(hipDeviceSynchronize());
-            per_phys.emplace_back(phys, have);
-        }
-        g->head[p] = have;
-    }
-    return per_phys.empty() ? 0 : (int64_t)bytes;
 }
 
 static int frag_ip_chunks(const GPUGraphStorage* g, int32_t rows) { return rows > 0 ? (int)((((int64_t)rows - 1) >> g->row_shift) + 1) : 1; }
@@ -270,7 +228,7 @@ int64_t GPUGraphStorage_ReplicateToDevices(GPUGraphStorage* g)
     if (!g || !g->csr_node_index_cpu || g->csr_location == LEGION_LOC_DEVICE) return 0; // already HBM resident
     replicate_table<int64_t>(g->csr_node_index_cpu, (int64_t)g->node_num + 1, g->partition_count, g->replica_indptr);
     replicate_table<int32_t>(g->csr_dst_node_ids_cpu, g->edge_num, g->partition_count, g->replica_indices);
-    return ((int64_t)g->node_num + 1) * 8 + g->edge_num * 4 + GPUGraphStorage_BuildHeadTables(g);
+    return ((int64_t)g->node_num + 1) * 8 + g->edge_num * 4;
 }
 
 void GPUGraphStorage_Finalize(GPUGraphStorage* g)
@@ -278,7 +236,6 @@ void GPUGraphStorage_Finalize(GPUGraphStorage* g)
     if (!g) return;
     free_replicas(g->replica_indptr);
     free_replicas(g->replica_indices);
-    free_replicas(g->head);
     for (size_t i = 0; i < g->frag.size(); i++) {
         if (!is_remote_device((int)i) || g->frag[i].imported) { DeviceGuard guard((int)i); free_fragment(g->frag[i]); }
         if (g->d_frag_tab[i]) { DeviceGuard guard((int)i); (void)hipFree(g->d_frag_tab[i]); g->d_frag_tab[i] = nullptr; }
@@ -288,12 +245,6 @@ void GPUGraphStorage_Finalize(GPUGraphStorage* g)
         host_free_space(g->csr_dst_node_ids_cpu);
         g->owns_csr = false;
     }
-}
-int32_t* GPUGraphStorage_GetHeadTable(const GPUGraphStorage* g, int32_t dev_id, int32_t* ints_per_entry)
-{
-    if (!g || dev_id < 0 || dev_id >= g->partition_count) return nullptr;
-    if (ints_per_entry) *ints_per_entry = 1 << g->head_shift;
-    return g->head[dev_id];
 }
 int32_t GPUGraphStorage_GetPartitionCount(const GPUGraphStorage* g) { return g->partition_count; }
 int64_t* GPUGraphStorage_GetCSRNodeIndexCPU(const GPUGraphStorage* g) { return g->csr_node_index_cpu; }
@@ -555,9 +506,6 @@ void GPUMemoryPool_AllocateScratch(GPUMemoryPool* p, int32_t total_num_nodes, in
     p->max_slots = (int32_t)max_slots;
     p->max_tiles = (int32_t)((max_slots + kTile - 1) / kTile);
     p->owns_scratch = true;
-#ifdef LEGION_POS32
-    if (max_slots > (int64_t)kPosValueMask || ids > (int64_t)kPosValueMask) { LEGION_ARG_ERROR("GPUMemoryPool_AllocateScratch: this -DLEGION_POS32 build holds 24-bit slot numbers / positions"); return; }
-#endif
     HIP_CHECK(hipMalloc(&p->pos_map, (size_t)total_num_nodes * sizeof(pos_t)));
     HIP_CHECK(hipMemset(p->pos_map, 0xFF, (size_t)total_num_nodes * sizeof(pos_t)));
     p->batch_serial = 0;

@@ -17,7 +17,6 @@ calls = [
  ("legion_peer_exchange_gather", lambda: L.legion_peer_exchange_gather(None, None, None, None, 0)),
  ("GPUGraphStorage_Build", lambda: L.GPUGraphStorage_Build(None, None)),
  ("GPUNodeStorage_Build", lambda: L.GPUNodeStorage_Build(None, None)),
- ("GPUGraphStorage_BuildHeadTables", lambda: L.GPUGraphStorage_BuildHeadTables(None)),
  ("GPUCache_CandidateSelection", lambda: L.GPUCache_CandidateSelection(None, 0, None, None)),
  ("GPUCache_CostModel", lambda: L.GPUCache_CostModel(None, 0, None, None, None, 1)),
  ("GPUCache_FillUp", lambda: L.GPUCache_FillUp(None, 0, None, None)),

@@ -247,41 +247,21 @@ def test_operator_plugin_api(K, oracle, small_ds):
     eng.close()
 
 
-@pytest.mark.parametrize("mode", ["0", "16", "32", "auto"])
-def test_head_table_layout_and_parity(K, oracle, synth, mode, monkeypatch):
-    """Round 3: the sampler reads a node's degree and -- when they fit -- its neighbours from ONE 64/128-byte head entry instead of
-    the indptr pair + the adjacency line (GPUGraphStorage_BuildHeadTables).  Layout vs numpy, and the batches are bit-identical to the
-    oracle with the table off, 16 ints, 32 ints and auto (degree-0 rows, rows that fit exactly, rows one too long, -1 neighbours)."""
-    L = K.lib()
-    monkeypatch.setenv("LEGION_HEAD_TABLE", mode)
+def test_degree_boundary_rows_parity(K, oracle, synth):
+    """Rows at every degree the sampler distinguishes -- 0, 1, below / at / above the fan-out, one 64-byte line of neighbours exactly,
+    one more, long rows -- and -1 neighbours (the reference skips them, Kernels.cu:411): bit-identical to the oracle."""
     spec = synth.spec_for("products", scale=0.004)
     ds = synth.generate(spec)
     V = spec.V
-    # reshape the degree sequence so that every boundary case occurs: 0, 1, 15, 16, 31, 32 neighbours and long rows
     rs = np.random.RandomState(11)
     deg = rs.choice([0, 1, 2, 7, 14, 15, 16, 17, 30, 31, 32, 33, 200], size=V, p=[.04, .08, .1, .2, .1, .1, .1, .08, .05, .05, .04, .03, .03]).astype(np.int64)
     indptr = np.concatenate([[0], np.cumsum(deg)])
     indices = rs.randint(0, V, size=int(indptr[-1])).astype(np.int32)
-    indices[rs.rand(len(indices)) < 0.002] = -1                          # the reference skips negative neighbour ids (Kernels.cu:411)
+    indices[rs.rand(len(indices)) < 0.002] = -1
     B, fan = 300, [10, 5, 3]
     seeds = dict(train=[(ds.train, ds.labels[ds.train])])
     eng = K.Engine(indptr, indices, ds.features, V, spec.F, seeds, B, fan)
     eng.alloc_features()
-    W = C.c_int32(0)
-    hp = L.GPUGraphStorage_GetHeadTable(eng.graph, 0, C.byref(W))
-    if mode == "0":
-        assert not hp
-    else:
-        assert hp and W.value == {"16": 16, "32": 32, "auto": 16 if indptr[-1] <= 24 * V else 32}[mode]
-        w = W.value
-        head = K.read_dev(hp, np.int32, V * w).reshape(V, w)
-        assert np.array_equal(head[:, 0], deg.astype(np.int32))
-        small = np.flatnonzero(deg < w)
-        for v in small[rs.choice(len(small), 400, replace=False)]:
-            assert np.array_equal(head[v, 1:1 + deg[v]], indices[indptr[v]:indptr[v + 1]]) and (head[v, 1 + deg[v]:] == 0).all()
-        big = np.flatnonzero(deg >= w)
-        start = head[big, 1].astype(np.uint32).astype(np.int64) | (head[big, 2].astype(np.int64) << 32)
-        assert np.array_equal(start, indptr[big])
     orc = oracle.OracleRunner(indptr, indices, ds.features, V, spec.F, B, fan)
     for it in (0, 2):
         ref = orc.run_batch(ds.train, ds.labels[ds.train], it)
@@ -290,16 +270,12 @@ def test_head_table_layout_and_parity(K, oracle, synth, mode, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("F,lanes", [(100, "auto"), (100, "1"), (36, "1"), (7, "auto"), (52, "1")])
-def test_padded_row_pitch_gathers_the_same_bytes(K, oracle, synth, F, lanes, monkeypatch):
+@pytest.mark.parametrize("F", [100, 36, 7, 52])
+def test_padded_row_pitch_gathers_the_same_bytes(K, oracle, synth, F):
     """an HBM feature table whose rows are padded to a 128-byte-aligned pitch (legion_row_pitch; F = 100 ->
-    128 floats) and the row-aligned lane layout of k_gather must deliver exactly the dense rows -- the trainer-facing buffer stays
-    [n, F].  F = 7: scalar path with a pitch; F = 36 / 52: float4 path, C = 9 / 13 lanes per row."""
+    128 floats) must deliver exactly the dense rows -- the trainer-facing buffer stays [n, F].  F = 7: scalar path with a pitch;
+    F = 36 / 52: float4 path, C = 9 / 13 lanes per row."""
     L = K.lib()
-    if lanes != "auto":
-        monkeypatch.setenv("LEGION_GATHER_ROW_LANES", lanes)
-    else:
-        monkeypatch.delenv("LEGION_GATHER_ROW_LANES", raising=False)
     spec = synth.spec_for("products", scale=0.004)
     ds = synth.generate(spec)
     V = spec.V
@@ -929,8 +905,8 @@ def test_randomised_differential(K, oracle, seed):
 def test_randomised_clique_cache_differential(K, oracle, seed, monkeypatch):
     """The cached path under random configurations (S5 / S6 / S8 / S9): random graph, feature width (odd, not a multiple of 4, not a
     whole number of 128-byte lines), hop count and fan-outs, clique size Kg in {1, 2, 4, 8} with one or two cliques, forced node / edge
-    capacities from 0 to "more than V", shard / fragment chunk sizes, head table on or off, in-kernel or bulk-copy peer gather, FindFeat
-    as a lookup pass or fused into the gather (one probe per row and wave, 1 / 2 / 4 work items per lane) --
+    capacities from 0 to "more than V", shard / fragment chunk sizes, in-kernel or bulk-copy peer gather, FindFeat as a lookup pass
+    (every batch hit-sampled: LEGION_CACHE_HIT_PERIOD=1) or fused into the gather (one probe per row and wave) --
     pre-sampling hotness, ranking, id -> slot maps and every steady-state batch of every GPU bit-identical to the oracle."""
     rng = np.random.RandomState(7000 + seed)
     L = K.lib()
@@ -954,9 +930,8 @@ def test_randomised_clique_cache_differential(K, oracle, seed, monkeypatch):
     parts = oracle.split_seeds(train, G)
     B = int(rng.randint(8, min(len(p) for p in parts)))
     steps = max(1, min((len(p) - 1) // B for p in parts))
-    for name, val in (("LEGION_SHARD_CHUNK_BYTES", rng.choice(["20000", "150000", None])), ("LEGION_HEAD_TABLE", rng.choice(["0", "auto"])),
-                      ("LEGION_PEER_GATHER", rng.choice(["exchange", None])),
-                      ("LEGION_GATHER_LOOKUP", ["pass", "fused1", "fused2", "fused4"][seed % 4])):     # FindFeat as a pass / inside the gather
+    for name, val in (("LEGION_SHARD_CHUNK_BYTES", rng.choice(["20000", "150000", None])), ("LEGION_PEER_GATHER", rng.choice(["exchange", None])),
+                      ("LEGION_CACHE_HIT_PERIOD", ["1", None][seed % 2])):     # FindFeat as a pass (sampled batches) / inside the gather
         if val is None:
             monkeypatch.delenv(name, raising=False)
         else:
@@ -1094,7 +1069,7 @@ def test_ipc_exports_above_the_limit_are_refused(K, small_ds, monkeypatch):
     with pytest.raises(RuntimeError, match="HIP-IPC limit"):
         K.check()
     # ... while a FEATURE buffer above it is built from chunks and mapped contiguously (end to end: test_gpu_ipc.py)
-    monkeypatch.setenv("LEGION_HANDOFF_CHUNK_BYTES", "131072")
+    monkeypatch.setenv("LEGION_SHARD_CHUNK_BYTES", "131072")
     L.IPCEnv_InitializeFeaturesBuffer(env, 0, 1000, ds.spec.F, 0, 1)          # 400 kB = 4 chunks
     K.check()
     p = L.IPCEnv_GetFloatFeatures(env, 0, 0)

@@ -251,7 +251,7 @@ class Budget:
         return got if got >= least else 0.0
 
 
-LEG_LEAST_S = {"unified_cache": 60.0, "served": 40.0, "served_all": 60.0}     # a leg that cannot get this much is skipped (default: 30 s)
+LEG_LEAST_S = {"unified_cache": 60.0, "served": 40.0, "served_all": 60.0, "partitioned_csr_host_spill": 90.0}     # a leg that cannot get this much is skipped (default: 30 s)
 
 
 def run_budgeted(c, line, guard, name, want, fn):
@@ -375,9 +375,15 @@ def worker(args):
         raise
     if rank == 0:
         sv = line["extra_legs"].get("served") or {}
-        if isinstance(sv, dict) and sv.get("value"):      # the headline batches as a trainer sees them, next to `value` (serial) and `value_overlap` (two streams, in-process)
+        if isinstance(sv, dict) and sv.get("value"):      # the headline batches as a trainer sees them, next to `value` (serial) and `value_overlap` (two streams, in-process):
+            # value_served = a consumer that READS every served row and edge before it hands the pipe back; value_served_null = the hand-off alone
             line["value_served"], line["ms_per_step_served"] = sv["value"], sv["ms_per_step"]
+            nul = sv.get("null_consumer") or {}
+            if nul.get("value"):
+                line["value_served_null"], line["ms_per_step_served_null"] = nul["value"], nul["ms_per_step"]
         line["time_budget"] = {"budget_s": args.time_budget, "used_s": round(time.time() - c.budget.t0, 1)}
+        if own_audit_counts(L) is not None:     # $LEGION_DEVICE_AUDIT=1 (a rehearsal, never a measurement): what rank 0's library saw
+            line["device_audit"] = own_audit_counts(L)
         emit_line(line)
     if world > 1:
         torch.distributed.barrier()
@@ -547,7 +553,8 @@ class LegGuard:
             timer.cancel()
 
 
-N1_LEGS = ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]   # run order: graph re-use first
+N1_LEGS = ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr", "partitioned_csr_host_spill"]   # run order: graph re-use first
+PCIE_PEAK_GBPS = 64.0       # PCIe Gen5 x16, one direction (the MI355X host link): what pinned-host rows can arrive at
 NN_LEGS = ["lp", "uk_union", "served_all"]     # served_all last: it starts other processes on every GPU of the job
 
 
@@ -563,7 +570,7 @@ def extra_leg_names(c):
             return []
         return list(N1_LEGS) if c.world == 1 else list(NN_LEGS)
     names = [x for x in a.extra_legs.split(",") if x]
-    known = N1_LEGS + ["uk_union", "served_all"]
+    known = N1_LEGS + ["uk_union", "served_all"]      # (partitioned_csr_host_spill: N = 1 only -- 137 GB of pinned host memory per process)
     bad = [x for x in names if x not in known]
     if bad:
         raise SystemExit("bench.py: unknown --extra-legs %s" % bad)
@@ -578,7 +585,10 @@ def extra_leg(c, name):
       products_2hop    config 1's workload (the CPU-sampler baseline's) on the GPU, with its CPU legs beside it
       products_3hop    config 2
       partitioned_csr  config 4 on the GPUs of this run (= uk_union at N > 1): uk-union shape, {25,10}, the hottest 30 % of the adjacency
-                       rows as partitioned CSR fragments (k_sample<partitioned>), 10 % of the feature rows cached"""
+                       rows as partitioned CSR fragments (k_sample<partitioned>), 10 % of the feature rows cached
+      partitioned_csr_host_spill   config 4 as BASELINE.json states it ("CSR sharded across GPUs + pinned-host spillover"): the same leg with
+                       the 137 GB feature table in pinned, device-mapped HOST memory behind the 10 % HBM cache (GPUGraphStore.cu:264-265,315;
+                       misses read over PCIe in-kernel, Kernels.cu:692-699): ms / batch, hit rate, miss rows, PCIe GB/s against the link peak"""
     import copy
     a = copy.copy(c.args)
     c2 = copy.copy(c)
@@ -594,7 +604,19 @@ def extra_leg(c, name):
             setattr(c, k, getattr(c2, k))      # the previous graph is gone: later legs see this one
 
     if name == "served":
-        return served_leg(c, c.args.workload, c.fan, c.head)
+        # the headline batches as a trainer sees them.  Two consumers, same server, same schedule: one that READS what it is served before it hands
+        # the pipe back (the figure that counts: a working trainer reads every row from the same HBM the next batch is produced in) and the null
+        # consumer (the hand-off alone: the ceiling of this formulation)
+        out = served_leg(c, c.args.workload, c.fan, c.head, consumer="reading")
+        if c.budget.left() > 60.0:
+            try:
+                nul = served_leg(c, c.args.workload, c.fan, c.head, consumer="null")
+                out["null_consumer"] = {k: nul[k] for k in ("value", "ms_per_step", "windows", "window_ms_min_median_max", "ratio_to_alt_schedule_levels",
+                                                            "ratio_to_alt_schedule", "served_batches_equal_the_timed_ones", "pipeline_frac")}
+                out["ratio_to_null_consumer"] = round(out["ms_per_step"] / nul["ms_per_step"], 4)
+            except Exception as ex:   # noqa: BLE001 -- the reading consumer's figure stays valid
+                out["null_consumer"] = {"error": repr(ex)[:300]}
+        return out
     if name == "served_all":
         # the last leg: every rank gives its graph back first (uk-union: 160 GB per GPU), the server generates its own replica on every GPU
         import torch
@@ -652,6 +674,27 @@ def extra_leg(c, name):
             except Exception as ex:   # noqa: BLE001 -- reported baseline only
                 out["cpu_baseline"] = {"value": None, "unit": "edges/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(ex)[:200]}
         return out
+    if name == "partitioned_csr_host_spill":
+        a.workload, a.fanout, a.task, a.topo_frac, a.cache_frac, a.no_exchange_leg, a.table = "uk-union", "25,10", "node", 0.3, 0.10, True, "host"
+        c2.fan, c2.H = [25, 10], 2
+        t_pin = time.time()
+        adopt_graph("uk-union")          # generates the graph in HBM, then moves the feature table into pinned host memory (load_workload, --table host)
+        pin_s = time.time() - t_pin
+        leg = run_leg(c2, unified=True, headline=False, min_time=a.min_time)
+        out_hs = leg_summary(c2, leg, f"uk-union-shape graph, CSR sharded over the {c.world}-GPU clique (30 % of the adjacency rows in partitioned fragments), "
+                                      f"the {c2.spec.V * c2.spec.F * 4 / 1e9:.0f} GB feature table in PINNED HOST memory behind a unified HBM cache of 10 % of its rows: "
+                                      "hits from the HBM shard, misses read in-kernel over PCIe (BASELINE config 4 as stated)")
+        rl = (leg["cache_info"] or {}).get("rows_last_batch") or {}
+        rows = sum(rl.get(k, 0) for k in ("own_shard", "peer_shards", "backing_table"))
+        g_ms = float(leg["g_ms"].mean()) if len(leg["g_ms"]) else None
+        if rows and g_ms:
+            miss = rl.get("backing_table", 0)
+            gbps = miss * c2.spec.F * 4 / (g_ms * 1e-3) / 1e9
+            out_hs["host_spill"] = {"rows_last_batch": rows, "miss_rows_last_batch": miss, "hit_rate": round(1.0 - miss / rows, 4),
+                                    "pcie_read_GBps": round(gbps, 2), "pcie_peak_GBps": PCIE_PEAK_GBPS, "pcie_frac_of_peak": round(gbps / PCIE_PEAK_GBPS, 4),
+                                    "how": "miss rows of the last batch x 4F bytes / the gather's average HIP-event time (lookups included)"}
+        out_hs["table_generate_and_pin_s"] = round(pin_s, 1)
+        return out_hs
     # uk_union / partitioned_csr: legion_server.py:23-37 shape, 2-hop GCN fan-out; the hottest 30 % of the adjacency rows as partitioned CSR
     # fragments over the N-GPU clique (GPU_Memory_Graph_Storage.cu:98-133), 10 % of the feature rows in the unified cache, the rest from the
     # HBM replica (a pinned-host backing table of 137 GB per process is not attempted here; tests/test_gpu_full_shape.py covers it)
@@ -681,16 +724,25 @@ def extra_leg(c, name):
 
 
 def served_consumer(argv):
-    """Child process of the `served` leg: a trainer-side null consumer on the C-ABI IPC client (legion_ipc_client_*: what ipc_service
-    binds) -- wait for the batch (sem_w), read its counters, hand the pipe back (sem_r); the reference's get_next / synchronize without a
-    model in between (ipc_cuda_kernel.cu:98-107,178-230).  No torch.  One JSON object on stdout: the arrival time, edges and rows of every batch."""
+    """Child process of the `served` legs: a trainer-side consumer on the C-ABI IPC client (legion_ipc_client_*: what ipc_service binds).
+    argv: hops epochs [gpu [mode F workload scale]].
+      mode null     wait for the batch (sem_w), read its counters, hand the pipe back (sem_r): the reference's get_next / synchronize with
+                    nothing in between (ipc_cuda_kernel.cu:98-107,178-230) -- the hand-off alone.
+      mode reading  ... and, before the pipe goes back, READ what was served the way a trainer does (legion_graphsage.py:72-89 touches every
+                    feature row and both COO arrays of the batch before torch.cuda.synchronize()): the whole [nc9, F] feature view and both
+                    COO arrays are summed word by word on a stream of this process (legion_sum_words: one 16-byte-per-lane read kernel,
+                    ~1 GB per papers100M batch) -- the memory traffic of a training step without the model, competing with the server's
+                    next batch for the same HBM.  Batch 1's sums are checked: the COO sums against a host copy of the arrays, the feature
+                    sum against the generator's closed form of the rows the batch names (legion-1_amd/synth.py) -- the read is real.
+    No torch.  One JSON object on stdout: the arrival time, edges and rows of every batch (+ the checksums)."""
     import ctypes as C
     import legion1_amd.capi as K
     hops, epochs = int(argv[0]), int(argv[1])
-    gpu = int(argv[2]) if len(argv) > 2 else 0        # logical GPU of the server this consumer is the trainer of (served_all: one per GPU)
+    gpu = int(argv[2]) if len(argv) > 2 and int(argv[2]) >= 0 else 0     # logical GPU of the server this consumer is the trainer of (served_all: one per GPU)
+    mode = argv[3] if len(argv) > 3 else "null"
     lib = K.lib()
     lib.SetGPUDevice(gpu)                             # physical device gpu % visible devices, as the server maps it
-    if len(argv) > 2:
+    if len(argv) > 2 and int(argv[2]) >= 0:
         os.environ["LEGION_IPC_DEVICE"] = str(gpu)    # row of the handle table (differs from the physical device on a shared GPU)
     c = C.c_void_p(lib.legion_ipc_client_open(-1))
     K.check()
@@ -699,16 +751,74 @@ def served_consumer(argv):
     total = (steps[0] + steps[1]) * epochs + steps[2]
     nc, ec = (C.c_int32 * 16)(), (C.c_int32 * 16)()
     t, edges, nodes = [], [], []
-    for _ in range(total):
+    reading = mode == "reading"
+    check = None
+    if reading:
+        F = int(argv[4])
+        stream = lib.d_stream_create()
+        acc = K.DevBuf(64)
+        lib.d_memset_async(acc.ptr, 0, 64, stream)
+        rows_cap = lib.legion_ipc_client_feature_rows(c)
+
+        def read_acc():
+            lib.d_stream_sync(stream)
+            return acc.to_numpy(np.uint64, 3)
+    for b in range(total):
         lib.legion_ipc_client_wait(c)
         lib.legion_ipc_client_read_counters(c, nc, ec)
         t.append(time.perf_counter())
-        edges.append(ec[2 + hops])
-        nodes.append(nc[5 + 2 * hops])
-        lib.legion_ipc_client_post(c)
+        n, e = nc[5 + 2 * hops], ec[2 + hops]
+        edges.append(e)
+        nodes.append(n)
+        if reading and n > 0:
+            rows = min(n, rows_cap) if rows_cap > 0 else n
+            before = read_acc() if b == 1 else None
+            lib.legion_sum_words(stream, lib.legion_ipc_client_buffer(c, 1), rows * F * 4, acc.ptr)
+            lib.legion_sum_words(stream, lib.legion_ipc_client_buffer(c, 3), e * 4, acc.ptr + 8)
+            lib.legion_sum_words(stream, lib.legion_ipc_client_buffer(c, 4), e * 4, acc.ptr + 16)
+            if b == 1:      # a batch of the warm-up part of epoch 0 (outside every timed window): keep what is needed to check the sums afterwards
+                check = {"batch": b, "rows": int(rows), "edges": int(e), "got": (read_acc() - before).tolist(),
+                         "ids": K.read_dev(lib.legion_ipc_client_buffer(c, 0), np.int32, rows),
+                         "src": K.read_dev(lib.legion_ipc_client_buffer(c, 3), np.int32, e), "dst": K.read_dev(lib.legion_ipc_client_buffer(c, 4), np.int32, e)}
+        lib.legion_ipc_client_post(c)                 # hipDeviceSynchronize (the reads above are done) + sem_post
+    K.check()
     lib.legion_ipc_client_close(c)
-    sys.stdout.write(json.dumps({"steps": list(steps), "hops": hops, "t0": t[0], "t": [round(x - t[0], 7) for x in t],
-                                 "edges": edges, "nodes": nodes}) + "\n")
+    out = {"steps": list(steps), "hops": hops, "t0": t[0], "t": [round(x - t[0], 7) for x in t], "edges": edges, "nodes": nodes, "consumer": mode}
+    if reading:
+        import legion1_amd.synth as S
+        words = lambda a: int(np.ascontiguousarray(a).view(np.uint32).astype(np.uint64).sum(dtype=np.uint64))   # noqa: E731
+        ok = None
+        if check is not None:
+            spec = S.spec_for(argv[5], scale=float(argv[6]))
+            want_f = 0
+            for i in range(0, check["rows"], 1 << 16):      # the generator's closed form of the rows the batch names, 65536 rows at a time
+                want_f = (want_f + words(S.features(spec, check["ids"][i:i + (1 << 16)]))) & 0xFFFFFFFFFFFFFFFF
+            want = [want_f, words(check["src"]), words(check["dst"])]
+            ok = [int(g) == int(w) for g, w in zip(check["got"], want)]
+            out["checksum"] = {"batch": check["batch"], "rows": check["rows"], "edges": check["edges"], "features_equal_the_generators_rows": ok[0],
+                               "coo_src_equal_host_copy": ok[1], "coo_dst_equal_host_copy": ok[2], "sum_of_feature_words": str(check["got"][0])}
+        out["read_bytes"] = [int(min(n, rows_cap) if rows_cap > 0 else n) * F * 4 + 8 * int(e) for n, e in zip(nodes, edges)]
+        lib.d_stream_destroy(stream)
+        acc.free()
+    sys.stdout.write(json.dumps(out) + "\n")
+
+
+def server_audit_line(log_text):
+    """The summary a `legion` server leaves under $LEGION_DEVICE_AUDIT=1 (csrc/audit.h), parsed; None when the audit was off."""
+    import re
+    m = re.search(r"Device audit: (\d+) checks, (\d+) violations, (\d+) unattributed, (\d+) launches with peer arguments", log_text)
+    return dict(zip(("checks", "violations", "unattributed", "peer_launches"), (int(x) for x in m.groups()))) if m else None
+
+
+def own_audit_counts(L):
+    """The logical-device audit of THIS process's library ($LEGION_DEVICE_AUDIT=1), or None."""
+    import ctypes
+    if not L.legion_audit_enabled():
+        return None
+    cnt = (ctypes.c_int64 * 4)()
+    L.legion_audit_counts(cnt)
+    return {"checks": cnt[0], "violations": cnt[1], "unattributed": cnt[2], "peer_launches": cnt[3],
+            "first_violations": [L.legion_audit_message(i).decode()[:300] for i in range(min(3, L.legion_audit_message_count()))]}
 
 
 def served_deadline(c):
@@ -733,13 +843,15 @@ def served_schedule_windows(t, train_step, valid_step, epochs, K_steps, warm):
     return out
 
 
-def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
+def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0, consumer="null"):
     """The whole path through the reference's surface, as a trainer sees it: the `legion` server binary -- started as a
     FRESH child process, dataset source `synth:<workload>` (the tables generated in its own HBM by the legion_synth_* calls this file uses),
     pre-sampling epoch, then its default software-pipelined RunOnce loop (runner.cpp; Server.cu:301-328) -- hands every batch of its schedule
     to a second child, a null consumer on legion_ipc_client_* (CUDA_IPC_Service.cu:289-297 / ipc_cuda_kernel.cu:98-107).  Reported: the
     consumer-side ms per training batch (median window of K batches, arrival to arrival), edges/s as the consumer sees them, the schedule,
-    and the ratio to `alt_schedule_levels` -- the same two-stream schedule run by this process without the hand-off."""
+    and the ratio to `alt_schedule_levels` -- the same two-stream schedule run by this process without the hand-off.
+    consumer = "reading": the consumer reads every served feature row and both COO arrays on its own stream before it hands the pipe back
+    (served_consumer; the memory traffic of legion_graphsage.py:72-89 without the model) and checks one batch's sums."""
     import shutil
     import tempfile
     args = c.args
@@ -790,8 +902,8 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
                 raise RuntimeError("the server was not ready in time: " + open(log_path, errors="ignore").read()[-400:])
             time.sleep(0.05)
         ready_s = time.time() - t0
-        cons = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--served-consumer", str(H), str(epochs)], env=env,
-                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        cons = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--served-consumer", str(H), str(epochs), "-1", consumer, str(spec.F), workload,
+                                 repr(args.scale)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         c.children.append(cons)
         try:
             out, err = cons.communicate(timeout=max(1.0, deadline - time.time()))
@@ -813,6 +925,12 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
     ts, vs, es = got["steps"]
     if ts != train_step or len(got["t"]) != (ts + vs) * epochs + es:
         raise RuntimeError("served schedule %s x %d epochs does not match the shape (train_step %d)" % (got["steps"], epochs, train_step))
+    reading = None
+    if consumer == "reading":
+        ck = got.get("checksum") or {}
+        if not (ck.get("features_equal_the_generators_rows") and ck.get("coo_src_equal_host_copy") and ck.get("coo_dst_equal_host_copy")):
+            raise RuntimeError("the reading consumer's checksums of batch 1 do not match what was served: %s" % ck)
+        reading = {"checksum": ck}
     t, edges, nodes = got["t"], np.asarray(got["edges"], np.int64), np.asarray(got["nodes"], np.int64)
     wins = served_schedule_windows(t, ts, vs, epochs, K_win, warm)
     secs = np.array([w[0] for w in wins])
@@ -828,9 +946,16 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
     lv = (ref_leg.get("alt_levels") or {}).get("ms_per_step")
     ov = (ref_leg.get("alt") or {}).get("ms_per_step") if (ref_leg.get("alt") or {}).get("pipeline") == "overlap" else None
     train_t = float(sum(t[e * (ts + vs) + ts - 1] - t[max(e * (ts + vs) - 1, 0)] for e in range(epochs)))
+    if reading is not None:
+        rb = np.asarray(got["read_bytes"], np.int64)[is_train]
+        reading.update(read_GB_per_batch=round(float(rb.mean()) / 1e9, 4), consumer_read_GBps=round(float(rb.mean()) / (ms * 1e-3) / 1e9, 1),
+                       reads="every served feature row ([nc9, F] view) and both COO arrays, summed word by word on the consumer's own stream before the pipe "
+                             "goes back (legion_sum_words): the memory traffic of legion_graphsage.py:72-89 without the model")
     return {"what": "the `legion` server binary (fresh child process; dataset source %s: tables generated in its HBM; pre-sampling epoch; default "
-                    "software-pipelined RunOnce, 2 streams, depth-2 pipes) serving a null consumer process over shm + semaphores + HIP-IPC buffers "
-                    "(legion_ipc_client_*: wait, read counters, post); times are the CONSUMER's clock, arrival to arrival" % src,
+                    "software-pipelined RunOnce, 2 streams, depth-2 pipes) serving a %s consumer process over shm + semaphores + HIP-IPC buffers "
+                    "(legion_ipc_client_*: wait, read counters, %spost); times are the CONSUMER's clock, arrival to arrival"
+                    % (src, consumer, "read the whole batch, " if reading is not None else ""),
+            "consumer": consumer, "reading_consumer": reading,
             "value": round(e_mean / (ms * 1e-3), 1), "unit": "edges/s", "ms_per_step": round(ms, 4),
             "feature_GBps": round(n_mean * 4 * spec.F / (ms * 1e-3) / 1e9, 2), "batch": B, "fanout": list(fan), "V": spec.V, "F": spec.F,
             "schedule": {"train_steps": ts, "valid_steps": vs, "test_steps": es, "epochs": epochs, "batches_served": len(t),
@@ -854,6 +979,7 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0):
             "server_ready_s": round(ready_s, 2), "server_tables": "generated in HBM" if "Tables generated in HBM" in log_text else "?",
             "server_cache": next((ln.strip() for ln in log_text.splitlines() if ln.startswith("Feat capacity")), None) if cache_bytes > 0 else None,
             "server_first_epoch_s": next((float(ln.split(":")[1].split()[0]) for ln in log_text.splitlines() if ln.startswith("First epoch cost")), None),
+            "server_device_audit": server_audit_line(log_text),
             "processes": "bench.py (idle) + legion + consumer"}
 
 
@@ -956,6 +1082,7 @@ def served_all_leg(c):
             "gpu0_batches_equal_rank0s_timed_ones": same,
             "server_ready_s": round(ready_s, 2),
             "server_gather": [ln.split("Runner gather:")[1].strip()[:60] for ln in log_text.splitlines() if "Runner gather:" in ln][:N],
+            "server_device_audit": server_audit_line(log_text),
             "shared_device": bool(c.shared_device), "processes": "%d bench ranks (idle) + legion + %d consumers" % (N, N)}
 
 
@@ -1032,6 +1159,8 @@ def run_leg(c, unified, headline, min_time=None, with_alt=False):
     me = rank if unified else 0          # the one this process drives
     for g in range(G):
         L.legion_set_device_map(g, c.local_rank)
+    if me != 0:
+        L.legion_audit_alias(0, me)     # one process per GPU: this process's device is GPU 0 of its replicated engine and GPU <rank> of the clique
     L.SetGPUDevice(me)
     n_mine = c.n_mine
     empty = (np.zeros(0, np.int32), np.zeros(0, np.int32))

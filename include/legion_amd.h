@@ -65,6 +65,25 @@ int32_t legion_physical_device(int32_t logical_dev);
  * exactly like the reference's NVLink peer loads (Kernels.cu:395-409,698). */
 void legion_set_remote_device(int32_t logical_dev, int is_remote);
 int legion_is_remote_device(int32_t logical_dev);
+/* Logical-device audit ($LEGION_DEVICE_AUDIT=1, read when the library loads; csrc/audit.h has the rules).  The reference runs one
+ * thread per GPU under cudaSetDevice(own) and lets the clique's GPUs read each other's shards through peer access enabled all-pairs
+ * (Server.cu:87-95,119-127, GPUGraphStore.cu:145-168, GPU_Memory_Graph_Storage.cu:98-133, GPUCache.cu:769-826).  With several
+ * logical GPUs mapped onto ONE physical device (legion_set_device_map) a stream, event, allocation or launch made under the wrong
+ * device still works; under the audit every such resource carries the logical GPU it was created under and every launch, copy,
+ * event record, stream wait, graph launch and pointer table is checked against the logical GPU current on the calling thread
+ * (SetGPUDevice; the library's own scopes).  A violation is a sticky error (legion_last_error) naming the call site.
+ * counts = {checks, violations, resources / launches that could not be attributed (no logical GPU selected, foreign memory),
+ * kernel launches with a table argument in a peer's memory}.  legion_audit_report prints one summary line (+ the first violations)
+ * to the library's log and returns the number of violations. */
+int legion_audit_enabled(void);
+void legion_audit_counts(int64_t counts[4]);
+int32_t legion_audit_message_count(void);
+const char* legion_audit_message(int32_t i);
+void legion_audit_reset(void);
+int64_t legion_audit_report(void);
+/* one process per GPU: the process's only device is logical GPU 0 of a replicated engine and logical GPU <rank> of a clique engine --
+ * a and b (mapped to the same physical device) name the same device in THIS process; returns 0, -1 if they do not */
+int legion_audit_alias(int32_t a, int32_t b);
 
 /* ---- raw device helpers: src/Kernels.cuh:24-45 (same names) ------------------------------ */
 void* d_alloc_space(int64_t num_bytes);
@@ -230,6 +249,9 @@ int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p);
  * entry = (epoch << 32) | value with epoch = 0xFFFFFFFF - batch serial; an entry whose epoch is not
  * the running batch's is "not in the batch"; value < 0x80000000 is the node's index in sampled_ids. */
 uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p);
+/* cand[idx] of the hop that ran last: the neighbour sampler slot idx drew, -1 = no draw (degree < fan-out, padded source); what the
+ * duplicate census reads (profiles/dedup_census.py) */
+int32_t* GPUMemoryPool_GetCandidateBuffer(const GPUMemoryPool* p);
 /* batches started on this pool (the table epoch is 0xFFFFFFFF - serial); settable to exercise the wrap-around */
 uint32_t GPUMemoryPool_GetBatchSerial(const GPUMemoryPool* p);
 void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial);
@@ -413,6 +435,12 @@ int32_t* IPCEnv_GetEdgeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
  * IPCEnv_SetMirror fills the mirror from the host (poisoned pipe). */
 void IPCEnv_MirrorCounters(IPCEnv* e, int32_t dev_id, int32_t current_pipe, void* stream);
 void IPCEnv_SetMirror(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t nc_fill, int32_t ec_fill);
+/* nc[word] of the batch about to be posted, from the mirror IPCEnv_MirrorCounters queued (wait for that copy first); -1: not queued.
+ * The runner compares nc[5 + 2H] with the rows of its feature buffer: a batch that reached more nodes had rows dropped by the bounded
+ * gather (kernels.hip k_gather: "never write past the buffer") and its trainer will refuse it -- the server says so, once, and counts. */
+int32_t IPCEnv_MirroredNodeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t word);
+/* the row capacity of a device's feature buffers as published to its trainer (set by IPCEnv_InitializeFeaturesBuffer) */
+void IPCEnv_SetFeatureRows(IPCEnv* e, int32_t device_id, int32_t rows);
 int IPCEnv_SlabPinned(IPCEnv* e);   /* 1: the slab is page-locked (hipHostRegister), IPCEnv_MirrorCounters queues real asynchronous copies */
 void IPCEnv_IPCPost(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
 void IPCEnv_IPCWait(IPCEnv* e, int32_t dev_id, int32_t current_pipe);
@@ -427,6 +455,9 @@ void IPCEnv_SetHops(IPCEnv* e, int32_t hops);
 /* Namespace for the POSIX shm / semaphore names ("" = the reference's literal names
  * "simpleIPCshm", "sem_r_D_P", "sem_w_D_P").  Also read from $LEGION_IPC_NAMESPACE. */
 void legion_ipc_set_namespace(const char* ns);
+/* Remove what a KILLED server of namespace `ns` left in /dev/shm -- the slab, its extension object, the 2 x depth named semaphores of
+ * each of `devices` GPUs (the reference only unlinks in Finalize, CUDA_IPC_Service.cu:319-320).  Harmless when nothing is there. */
+void legion_ipc_unlink_namespace(const char* ns, int32_t devices);
 
 /* ---- IPC service, trainer half: pytorch_extension/ipc_service.h + ipc_cuda_kernel.cu ------ */
 typedef struct LegionIPCClient LegionIPCClient;
@@ -473,6 +504,8 @@ void Runner_RunPreSc(Runner* r, RunnerParams* params);
 void Runner_RunOnce(Runner* r, RunnerParams* params);
 void Runner_Finalize(Runner* r, RunnerParams* params);
 GPUMemoryPool* Runner_GetMemoryPool(Runner* r);
+/* batches handed over with more nodes than the feature buffers hold rows (their last rows were not gathered; logged once) */
+int64_t Runner_ShortBatches(const Runner* r);
 void Runner_Delete(Runner* r);
 /* Whole server driven by a meta_config file (legion_server.py:58-59, GPUGraphStore.cu:190-223).
  * fanout may be NULL (reference default {25,10}, Server.cu:68-69). */
@@ -519,6 +552,10 @@ int32_t legion_synth_label_host(int32_t v, int32_t classes);                    
 int32_t legion_synth_seed_id_host(int64_t i, int32_t V, uint32_t M2, uint32_t C2);     /* == legion_synth_seed_ids, one index */
 /* streaming-copy kernel used by bench.py to report the measured HBM peak */
 void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes);
+/* *acc += the sum of the 32-bit words of [src, src + bytes) (u64, wrap-around; src 16-byte aligned, bytes a multiple of 4): what a trainer's
+ * read of a served batch costs without a model (legion_graphsage.py:72-89 reads every feature row and both COO arrays before it hands the
+ * pipe back) -- bench.py's reading consumer; exact and order-independent, so it doubles as a checksum of what was read */
+void legion_sum_words(void* stream, const void* src, int64_t bytes, uint64_t* acc);
 /* the same copy with an explicit variant (profiles/copy_sweep.py): 256-thread workgroups, `unroll` 16-byte chunks in
  * flight per lane (1, 2, 4, 8), nt bit 0 = non-temporal stores, bit 1 = non-temporal loads, contig = block-strided;
  * grid <= 0: one iteration per lane.  Returns 0, or -1 for an unknown variant. */

@@ -81,6 +81,13 @@ _SIGS = {
     "GPUCache_HitSamplingDone": (None, [vp, i32, vp]),
     "legion_set_remote_device": (None, [i32, C.c_int]),
     "legion_is_remote_device": (C.c_int, [i32]),
+    "legion_audit_enabled": (C.c_int, []),
+    "legion_audit_counts": (None, [vp]),
+    "legion_audit_message_count": (i32, []),
+    "legion_audit_message": (C.c_char_p, [i32]),
+    "legion_audit_reset": (None, []),
+    "legion_audit_report": (i64, []),
+    "legion_audit_alias": (C.c_int, [i32, i32]),
     "d_alloc_space": (vp, [i64]),
     "d_free_space": (None, [vp]),
     "host_alloc_space64": (vp, [i64]),
@@ -221,6 +228,9 @@ _SIGS = {
     "IPCEnv_HandoffSpinUs": (C.c_int, []),
     "IPCEnv_Finalize": (None, [vp]), "IPCEnv_GetTrainStep": (i32, [vp]), "IPCEnv_SetHops": (None, [vp, i32]),
     "legion_ipc_set_namespace": (None, [C.c_char_p]),
+    "legion_ipc_unlink_namespace": (None, [C.c_char_p, i32]),
+    "IPCEnv_MirroredNodeCounter": (i32, [vp, i32, i32, i32]),
+    "IPCEnv_SetFeatureRows": (None, [vp, i32, i32]),
     "legion_ipc_client_open": (vp, [i32]), "legion_ipc_client_wait": (None, [vp]),
     "legion_ipc_client_post": (None, [vp]), "legion_ipc_client_post_nosync": (None, [vp]), "legion_ipc_client_buffer": (vp, [vp, i32]),
     "legion_ipc_client_steps": (None, [vp, vp]), "legion_ipc_client_hops": (i32, [vp]), "legion_ipc_client_feature_rows": (i32, [vp]),
@@ -228,7 +238,7 @@ _SIGS = {
     "legion_runner_gather_estimate": (C.c_int, [i32, f64, f64, vp, vp]),
     "NewGPURunner": (vp, []), "Runner_Initialize": (None, [vp, vp]),
     "Runner_InitializeFeaturesBuffer": (None, [vp, vp]), "Runner_RunPreSc": (None, [vp, vp]),
-    "Runner_RunOnce": (None, [vp, vp]), "Runner_Finalize": (None, [vp, vp]), "Runner_GetMemoryPool": (vp, [vp]),
+    "Runner_RunOnce": (None, [vp, vp]), "Runner_Finalize": (None, [vp, vp]), "Runner_GetMemoryPool": (vp, [vp]), "Runner_ShortBatches": (i64, [vp]),
     "Runner_Delete": (None, [vp]),
     "NewGPUServer": (vp, []), "Server_SetFanout": (None, [vp, vp, i32]),
     "Server_SetMetaConfigPath": (None, [vp, C.c_char_p]), "Server_Initialize": (None, [vp, C.c_int]),
@@ -246,6 +256,8 @@ _SIGS = {
     "legion_synth_label_host": (i32, [i32, i32]),
     "legion_synth_seed_id_host": (i32, [i64, i32, u32, u32]),
     "legion_copy_f4": (None, [vp, vp, vp, i64]),
+    "legion_sum_words": (None, [vp, vp, i64, vp]),
+    "GPUMemoryPool_GetCandidateBuffer": (vp, [vp]),
     "legion_copy_f4_cfg": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, i32]),
     "legion_rng_probe": (None, [vp, vp, vp, vp, i32]),
 }
@@ -339,6 +351,7 @@ class Engine:
         for g in range(int(G)):
             L.legion_set_remote_device(g, 0 if g in self.local_devs else 1)
         self.L, self.G, self.V, self.F = L, int(G), int(V), int(F)
+        L.SetGPUDevice(self.local_devs[0])      # the shared tables below live on the first local GPU
         self.fanout = np.asarray(fanout, dtype=np.int32)
         self.hops = len(self.fanout)
         self.batch_size = int(batch_size)

@@ -10,6 +10,8 @@
 // (first batch, epoch / mode change, or after a host-driven batch on the same pool).
 #include "internal.h"
 
+#include "audit_hooks.h"
+
 using namespace legion;
 
 struct LegionBatchGraph {

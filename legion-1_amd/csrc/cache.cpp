@@ -20,6 +20,8 @@
 #include <cstring>
 #include <iostream>
 
+#include "audit_hooks.h"
+
 using namespace legion;
 
 #define MIN_INTERVAL 0.01 // GPUCache.cu:30
@@ -116,6 +118,7 @@ static void publish_shard_tables(GPUCache* c, int Ki)
         const int dev = Ki * Kg + j;
         if (is_remote_device(dev)) continue;
         DeviceGuard guard(dev);
+        LEGION_AUDIT_TABLE(dev, h.data(), h.size(), "feature shard chunk table");
         if (!c->d_shard_tab[dev]) HIP_CHECK(hipMalloc(&c->d_shard_tab[dev], h.size() * sizeof(float*)));
         HIP_CHECK(hipMemcpy(c->d_shard_tab[dev], h.data(), h.size() * sizeof(float*), hipMemcpyHostToDevice));
     }
@@ -503,6 +506,7 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
             HIP_CHECK(hipMalloc(&k->feat_map, (size_t)V * sizeof(int32_t)));
             HIP_CHECK(hipMalloc(&k->topo_owner, (size_t)V));
             HIP_CHECK(hipMalloc(&k->topo_row, (size_t)V * sizeof(int32_t)));
+            LEGION_AUDIT_OWNER(k->feat_map, dev, "FillUp: id -> slot map");
             launch_build_feat_map(nullptr, k->feat_map, c->QF[i], ncap, Kg, V);
             launch_build_topo_map(nullptr, k->topo_owner, k->topo_row, c->QT[i], ecap, Kg, i, V);
             free_shard(c, dev);
@@ -513,6 +517,7 @@ void GPUCache_FillUp(GPUCache* c, int cache_agg_mode, GPUNodeStorage* noder, GPU
                     HIP_CHECK(hipMalloc(&chunk, (size_t)rows * pitch * sizeof(float)));
                     if (pitch != F) HIP_CHECK(hipMemsetAsync(chunk, 0, (size_t)rows * pitch * sizeof(float), nullptr));
                     launch_feat_fill_up(nullptr, row0, rows, F, pitch, noder->float_attr_pitch, chunk, noder->float_attrs, c->QF[i], Kg, j, V);
+                    LEGION_AUDIT_OWNER(chunk, dev, "FillUp: feature shard chunk");
                     c->shard_chunks[dev].push_back(chunk);
                 }
                 c->float_feature_cache[dev] = c->shard_chunks[dev][0];

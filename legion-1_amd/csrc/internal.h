@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/legion_amd.h"
+#include "audit.h"
 
 namespace legion {
 
@@ -34,9 +35,9 @@ FILE* log_file();
 
 int physical_device(int logical);
 bool is_remote_device(int logical); // logical GPU driven by another process (one process per GPU)
-// RAII: switch to the physical device of a logical id, restore on scope exit
+// RAII: switch to a logical GPU (its physical device + the thread's logical current device), restore both on scope exit
 struct DeviceGuard {
-    int prev = -1;
+    int prev = -1, prev_logical = -1;
     explicit DeviceGuard(int logical);
     ~DeviceGuard();
 };

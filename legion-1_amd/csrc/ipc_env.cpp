@@ -28,6 +28,8 @@
 #include <thread>
 #include <unistd.h>
 
+#include "audit_hooks.h"
+
 using namespace legion;
 
 static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle must be 64 bytes (CUDA_IPC_Service.cu:34-37)");
@@ -53,8 +55,21 @@ struct shmExt {
     // trainer reads them with a blocking cudaMemcpy from the IPC device buffers (ipc_cuda_kernel.cu:195-196): on the legacy default stream that
     // copy waits for everything the trainer has queued.  A client that finds the magic set reads the mirror instead; buffers 5 / 6 stay valid.
     int32_t counters[LEGION_MAX_DEVICE][LEGION_PIPELINE_DEPTH][32];   // nc[16] | ec[16]
+    // What ties this object to the LIVE slab: the object is only unlinked by IPCEnv_Finalize, so after a killed server a server WITHOUT the
+    // extension (the reference's) would leave a stale one in place and a client would read stale hops / counters for good.  The server stores
+    // a copy of the slab's step counts and a checksum of the first handle it registers per device; a client ignores an extension that does not
+    // match the slab it attached to (it then behaves as against a reference server).
+    int32_t steps_copy[3];
+    uint32_t handle_sum[LEGION_MAX_DEVICE];   // FNV-1a of memHandle[dev][0][0]; 0 = nothing registered for that device yet
 };
 static const uint32_t kMirrorMagic = 0x4C474E43u;   // "LGNC"
+static uint32_t handle_checksum(const volatile void* h)
+{
+    uint32_t x = 2166136261u;
+    const volatile unsigned char* b = (const volatile unsigned char*)h;
+    for (size_t i = 0; i < sizeof(hipIpcMemHandle_t); i++) { x ^= b[i]; x *= 16777619u; }
+    return x ? x : 1u;
+}
 
 // $LEGION_IPC_NO_DEVICE=1 (test hook: build containers without a GPU, the host-sanitizer run of tests/test_ipc_env_cpu.py): the slab,
 // the named semaphores, the counter mirror and the poisoned-pipe protocol with no device call at all -- no hand-off buffer is
@@ -214,6 +229,7 @@ static void vmm_release(VmmRegion* r)
     if (r->listen_fd >= 0) close(r->listen_fd);
     for (int fd : r->fds) close(fd);
     if (r->va) {
+        if (audit::on()) audit::region_gone(r->va);
         (void)hipMemUnmap(r->va, r->desc.total);
         for (auto h : r->handles) (void)hipMemRelease(h);
         (void)hipMemAddressFree(r->va, r->desc.total);
@@ -270,6 +286,7 @@ static VmmRegion* vmm_create(int logical_dev, int pipe, size_t bytes)
         vmm_release(r);
         return nullptr;
     }
+    if (audit::on()) audit::region(r->va, total, logical_dev, __FILE__, __LINE__);
     r->server = std::thread(vmm_serve, r);
     return r;
 }
@@ -313,6 +330,17 @@ void legion_ipc_set_namespace(const char* ns)
 {
     g_namespace = ns ? ns : "";
     g_ns_init = true;
+}
+// Remove what a server of namespace `ns` that was KILLED left in /dev/shm (IPCEnv_Finalize never ran): the slab, its extension object and
+// the 2 x depth named semaphores of each of `devices` GPUs.  Safe to call when nothing is there.
+void legion_ipc_unlink_namespace(const char* ns, int32_t devices)
+{
+    const std::string p = ns ? ns : "";
+    shm_unlink(("/" + p + "simpleIPCshm").c_str());
+    shm_unlink(("/" + p + "simpleIPCshm_ext").c_str());
+    for (int d = 0; d < devices && d < LEGION_MAX_DEVICE; d++)
+        for (int q = 0; q < LEGION_PIPELINE_DEPTH; q++)
+            for (const char* rw : {"r", "w"}) sem_unlink(("/" + p + "sem_" + rw + "_" + std::to_string(d) + "_" + std::to_string(q)).c_str());
 }
 
 static void pin_slab(IPCEnv* e);
@@ -396,6 +424,7 @@ void IPCEnv_Coordinate(IPCEnv* e, const LegionBuildInfo* info)
     e->shm->steps[0] = e->train_step;
     e->shm->steps[1] = e->valid_step;
     e->shm->steps[2] = e->test_step;
+    if (e->ext) for (int i = 0; i < 3; i++) e->ext->steps_copy[i] = e->shm->steps[i];
 }
 
 int32_t IPCEnv_GetMaxStep(IPCEnv* e) { return ((e->train_step + e->valid_step) * e->epoch) + e->test_step; }
@@ -411,6 +440,7 @@ static void* ipc_alloc(volatile shmStruct* shm, int dev, int pipe, int which, si
         exit(EXIT_FAILURE);
     }
     HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    LEGION_AUDIT_OWNER(p, dev, "hand-off buffer");
     if (p) HIP_CHECK(hipIpcGetMemHandle((hipIpcMemHandle_t*)&shm->memHandle[dev][pipe][which], p));
     return p;
 }
@@ -431,6 +461,7 @@ void IPCEnv_InitializeSamplesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_i
         e->agg_dst[device_id].push_back(ipc_alloc(e->shm, device_id, i, 4, (size_t)num_ids * sizeof(int32_t)));
         e->node_counter[device_id].push_back(ipc_alloc(e->shm, device_id, i, 5, 16 * sizeof(int32_t)));
         e->edge_counter[device_id].push_back(ipc_alloc(e->shm, device_id, i, 6, 16 * sizeof(int32_t)));
+        if (i == 0 && e->ext) e->ext->handle_sum[device_id] = handle_checksum(&e->shm->memHandle[device_id][0][0]);
         if (e->node_counter[device_id][i]) HIP_CHECK(hipMemset(e->node_counter[device_id][i], 0, 16 * sizeof(int32_t)));
         if (e->edge_counter[device_id][i]) HIP_CHECK(hipMemset(e->edge_counter[device_id][i], 0, 16 * sizeof(int32_t)));
         // memory lock.  Stale semaphores of a crashed run are removed first (the reference only
@@ -475,6 +506,21 @@ void IPCEnv_InitializeFeaturesBuffer(IPCEnv* e, int32_t batch_size, int32_t num_
         e->float_features[device_id].push_back(p);
     }
     e->ext->feature_rows[device_id] = num_ids;
+}
+// the row capacity published to the trainers of a device (a server that re-sizes its feature buffers; tests)
+void IPCEnv_SetFeatureRows(IPCEnv* e, int32_t device_id, int32_t rows)
+{
+    if (e && e->ext && device_id >= 0 && device_id < e->device_count) e->ext->feature_rows[device_id] = rows;
+}
+// nc[word] of the batch about to be posted on (dev, pipe), from the host mirror IPCEnv_MirrorCounters queued (the caller has waited for
+// that copy); -1 when the mirror of this batch was not queued
+int32_t IPCEnv_MirroredNodeCounter(IPCEnv* e, int32_t dev_id, int32_t current_pipe, int32_t word)
+{
+    if (!e || !e->ext || dev_id < 0 || dev_id >= e->device_count || word < 0 || word >= 16) return -1;
+    const int q = current_pipe % e->pipeline_depth;
+    if (!e->mirror_fresh[dev_id][q]) return -1;
+    if (!e->shm_pinned) return e->mirror_stage[dev_id][q] ? e->mirror_stage[dev_id][q][word] : -1;
+    return e->ext->counters[dev_id][q][word];
 }
 
 int32_t IPCEnv_GetRawBatchsize(IPCEnv* e) { return e->raw_batch_size; }
@@ -738,25 +784,48 @@ LegionIPCClient* legion_ipc_client_open(int32_t device_id)
     if (!c->shm) { fprintf(log_file(), "Failed to create shared memory slab\n"); delete c; LEGION_ARG_ERROR("legion_ipc_client_open: shm"); return nullptr; }
     c->ext = (volatile shmExt*)shm_map(sizeof(shmExt), &c->ext_fd, ext_name(), false);     // never created by a client
     for (int i = 0; i < 3; i++) c->steps[i] = c->shm->steps[i];
-    c->hops = (c->ext && c->ext->hops > 0) ? c->ext->hops : 2;
     if (c->device >= LEGION_MAX_DEVICE) { LEGION_ARG_ERROR("legion_ipc_client_open: device id >= 8"); delete c; return nullptr; }
+    // an extension object that does not belong to the slab we attached to (left behind by a killed server, the slab re-created by a server
+    // without the extension): ignore it -- 2 hops, counters by device copy, no row bound: the reference's behaviour
+    if (c->ext && (c->ext->steps_copy[0] != c->steps[0] || c->ext->steps_copy[1] != c->steps[1] || c->ext->steps_copy[2] != c->steps[2] ||
+                   c->ext->handle_sum[c->device] != handle_checksum(&c->shm->memHandle[c->device][0][0]))) {
+        munmap((void*)c->ext, sizeof(shmExt));
+        close(c->ext_fd);
+        c->ext = nullptr; c->ext_fd = -1;
+    }
+    c->hops = (c->ext && c->ext->hops > 0) ? c->ext->hops : 2;
+    // feature buffers that arrive as chunk descriptors first: they need the server's socket, the one step that depends on a second party
+    for (int i = 0; i < LEGION_PIPELINE_DEPTH; i++) {
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const void*)&c->shm->memHandle[c->device][i][1], sizeof(h));
+        if (memcmp(&h, kVmmMagic, sizeof(kVmmMagic)) != 0) continue;
+        VmmDesc d;
+        memcpy(&d, &h, sizeof(d));
+        c->buf[i][1] = vmm_attach(c, i, d);
+        if (!c->buf[i][1]) {   // no trainer may run on a null feature buffer: close what was opened, post nothing
+            legion_ipc_client_close(c);
+            return nullptr;
+        }
+    }
     for (int i = 0; i < LEGION_PIPELINE_DEPTH; i++) {
         for (int w = 0; w < LEGION_MEMORY_USAGE; w++) {
+            if (c->buf[i][w]) continue;      // attached above
             hipIpcMemHandle_t h;
             memcpy(&h, (const void*)&c->shm->memHandle[c->device][i][w], sizeof(h));
-            if (w == 1 && memcmp(&h, kVmmMagic, sizeof(kVmmMagic)) == 0) {   // a chunk descriptor, not an IPC handle
-                VmmDesc d;
-                memcpy(&d, &h, sizeof(d));
-                c->buf[i][w] = vmm_attach(c, i, d);
-                if (!c->buf[i][w]) {   // no trainer may run on a null feature buffer: close what was opened, post nothing
-                    legion_ipc_client_close(c);
-                    return nullptr;
-                }
-                continue;
-            }
             static const hipIpcMemHandle_t zero{};
-            if (memcmp(&h, &zero, sizeof(h)) == 0) continue;     // the server registered no buffer in this slot (a features buffer before
-                                                                 // PreSc, Server.cu:33,273-282; $LEGION_IPC_NO_DEVICE): nothing to open
+            if (memcmp(&h, &zero, sizeof(h)) == 0) {
+                if (no_device()) continue;                       // the device-free test mode registers no buffers at all
+                // The server has not registered this buffer yet: the sample buffers appear in Runner_Initialize, the FEATURE buffers only
+                // after the pre-sampling epoch (Server.cu:33,273-282).  A trainer that attaches now would run on a null buffer and fault
+                // on the GPU in its first kernel; the reference fails in cudaIpcOpenMemHandle here.  Refuse, by name.
+                char msg[256];
+                snprintf(msg, sizeof(msg), "legion_ipc_client_open: the server has not registered buffer %d of pipe %d of GPU %d yet "
+                         "(start the trainer after \"System is ready for serving\")", w, i, c->device);
+                legion_ipc_client_close(c);
+                legion_clear_error();   // this is why the client is refused: let it be the error the caller reads
+                LEGION_ARG_ERROR(msg);
+                return nullptr;
+            }
             HIP_CHECK(hipIpcOpenMemHandle(&c->buf[i][w], h, hipIpcMemLazyEnablePeerAccess));
         }
     }

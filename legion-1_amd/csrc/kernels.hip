@@ -46,6 +46,8 @@
 #include <mutex>
 #include <cstring>
 
+#include "audit_hooks.h"
+
 namespace legion {
 
 // ------------------------------------------------------------------------------------------------
@@ -1128,6 +1130,7 @@ static uint32_t* pow_table()
         HIP_CHECK(hipMalloc(&tabs[dev], kTile * sizeof(uint32_t)));
         HIP_CHECK(hipMemcpy(tabs[dev], h.data(), kTile * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
+    LEGION_AUDIT_SHARE(tabs[dev], current_logical_device());   // one table per PHYSICAL device, whichever logical GPUs map to it
     return tabs[dev];
 }
 
@@ -1138,17 +1141,20 @@ void launch_seed(hipStream_t s, int32_t* batch_ids, int32_t* labels, int32_t bat
 {
     const int32_t bound = self_driven ? batch_size : size;
     int blocks = bound > 0 ? (bound - 1) / kBlock + 1 : 1;
+    LEGION_AUDIT_LAUNCH(s, "k_seed", LEGION_AW(batch_ids), LEGION_AW(labels), LEGION_AW(pos_map), LEGION_AW(ctl), LEGION_AW(nc), LEGION_AW(ec), LEGION_AW(aux_next), LEGION_AL(all_ids), LEGION_AL(all_labels));
     if (self_driven) k_seed<true><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec, aux_next, f_next, aux_cap);
     else k_seed<false><<<blocks, kBlock, 0, s>>>(batch_ids, labels, batch_size, size, counter, all_ids, all_labels, total_cap, pos_map, epoch, ctl, nc, ec, aux_next, f_next, aux_cap);
     HIP_CHECK_LAST();
 }
 void launch_set_cursor(hipStream_t s, BatchCtl* ctl, int32_t counter, uint32_t epoch)
 {
+    LEGION_AUDIT_LAUNCH(s, "k_set_cursor", LEGION_AW(ctl));
     k_set_cursor<<<1, 1, 0, s>>>(ctl, counter, epoch);
     HIP_CHECK_LAST();
 }
 void launch_advance(hipStream_t s, BatchCtl* ctl)
 {
+    LEGION_AUDIT_LAUNCH(s, "k_advance", LEGION_AW(ctl));
     k_advance<<<1, 1, 0, s>>>(ctl);
     HIP_CHECK_LAST();
 }
@@ -1165,6 +1171,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     constexpr int wg_per_cu = 4;
     const int grid = std::min(grid_for(max_tiles, 1, wg_per_cu), kMaxChunks);   // one chunk of tiles per k_mark workgroup (see k_mark)
     if (!b.aux_prepared) { // the previous launch prepared the slot states for another fan-out (or there was none)
+        LEGION_AUDIT_LAUNCH(s, "k_fill_aux", LEGION_AW(b.aux), LEGION_AL(b.nc));
         k_fill_aux<<<grid_for(slots_bound, kBlock * 4), kBlock, 0, s>>>(b.nc, count, b.aux, b.aux_cap);
         HIP_CHECK_LAST();
     }
@@ -1182,10 +1189,13 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     a.window = std::min(count - 1, 8);
     a.prefilter_from_op = 4;   // hop 1 goes straight to the atomic (see k_sample; moving the boundary lost: profiles/r04_sampler.md)
     const bool part = csr.topo_owner != nullptr;
+    // the whole CSR may be a peer's / the host's table; the fragment chunk tables, the id -> (owner, row) maps and every buffer of the pool are this GPU's
+    LEGION_AUDIT_LAUNCH(s, "k_sample", LEGION_AW(a.pos_map), LEGION_AW(a.cand), LEGION_AW(a.aux), LEGION_AW(a.tile_edge), LEGION_AW(a.edge_access_time), LEGION_AL(a.sampled_ids), LEGION_AL(a.agg_src_ids), LEGION_AL(a.nc), LEGION_AL(a.ec), LEGION_AL(a.ctl), LEGION_AL(a.pow_tab), LEGION_AL(csr.frag_indptr), LEGION_AL(csr.frag_indices), LEGION_AL(csr.topo_owner), LEGION_AL(csr.topo_row), LEGION_AR(csr.indptr), LEGION_AR(csr.indices));
     if (is_presc) k_sample<true, false><<<grid, kBlock, 0, s>>>(a);
     else if (part) k_sample<false, true><<<grid, kBlock, 0, s>>>(a);
     else k_sample<false, false><<<grid, kBlock, 0, s>>>(a);
     HIP_CHECK_LAST();
+    LEGION_AUDIT_LAUNCH(s, "k_mark", LEGION_AW(b.aux), LEGION_AW(b.tile_node), LEGION_AW(b.tile_pre), LEGION_AW(b.chunk_tot), LEGION_AW(b.hop_state), LEGION_AL(b.nc), LEGION_AL(b.ec), LEGION_AL(b.tile_edge));
     k_mark<<<grid, kBlock, 0, s>>>(b.nc, b.ec, count, b.aux, b.tile_edge, b.tile_node, b.tile_pre, b.chunk_tot, b.hop_state);
     HIP_CHECK_LAST();
     WriteArgs w;
@@ -1196,6 +1206,7 @@ void launch_sample_hop(hipStream_t s, const CsrTables& csr, const SamplerBuffers
     w.tile_pre = b.tile_pre; w.chunk_tot = b.chunk_tot; w.mark_grid = grid;
     // 17 KB of static LDS (the chunk prefix): 8 workgroups per CU
     const int wgrid = grid_for(max_tiles, 1, 8);
+    LEGION_AUDIT_LAUNCH(s, "k_write", LEGION_AW(w.hs), LEGION_AW(w.nc), LEGION_AW(w.ec), LEGION_AW(w.sampled_ids), LEGION_AW(w.agg_src_ids), LEGION_AW(w.agg_src_off), LEGION_AW(w.agg_dst_off), LEGION_AW(w.pos_map), LEGION_AW(w.aux_next), LEGION_AL(w.cand), LEGION_AL(w.aux), LEGION_AL(w.tile_edge), LEGION_AL(w.tile_node), LEGION_AL(w.tile_pre), LEGION_AL(w.chunk_tot), LEGION_AL(w.ctl));
     k_write<<<wgrid, kBlock, 0, s>>>(w);
     HIP_CHECK_LAST();
 }
@@ -1204,6 +1215,7 @@ void launch_find_feat(hipStream_t s, const int32_t* sampled_ids, int32_t* cache_
                       int32_t op_id, const int32_t* feat_map, int32_t bound)
 {
     const int l = (op_id - 1) / 2;
+    LEGION_AUDIT_LAUNCH(s, "k_find_feat", LEGION_AW(cache_offset), LEGION_AL(sampled_ids), LEGION_AL(nc), LEGION_AL(feat_map));
     k_find_feat<<<grid_for(bound, kBlock), kBlock, 0, s>>>(sampled_ids, cache_offset, nc, 3 + 2 * l, 4 + 2 * l, feat_map);
     HIP_CHECK_LAST();
 }
@@ -1212,6 +1224,7 @@ void launch_find_topo(hipStream_t s, const int32_t* input_ids, int8_t* part_inde
                       int32_t batch_size, const int8_t* topo_owner, const int32_t* topo_row)
 {
     if (batch_size <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_find_topo", LEGION_AW(part_index), LEGION_AW(part_offset), LEGION_AL(input_ids), LEGION_AL(topo_owner), LEGION_AL(topo_row));
     k_find_topo<<<grid_for(batch_size, kBlock), kBlock, 0, s>>>(input_ids, part_index, part_offset, batch_size, topo_owner, topo_row);
     HIP_CHECK_LAST();
 }
@@ -1222,6 +1235,8 @@ void launch_gather(hipStream_t s, const GatherArgs& g, int32_t rows_bound)
     GatherKArgs a;
     a.g = g;
     a.div_cap = FastDiv((uint32_t)(g.cache_capacity > 0 ? g.cache_capacity : 1));
+    // the backing table may be the host's or a peer's; the shard chunk TABLE and the id -> slot map are this GPU's (the chunks it names: audited where it is published)
+    LEGION_AUDIT_LAUNCH(s, "k_gather", LEGION_AW(g.dst), LEGION_AW(g.row_ptr), LEGION_AW(g.rows_seen), LEGION_AW(g.hit_stats), LEGION_AL(g.sampled_ids), LEGION_AL(g.nc), LEGION_AL(g.feat_map), LEGION_AL(g.shard_tab), LEGION_AR(g.table));
     // cache chunks are hipMalloc'ed (256-byte aligned) and hold whole rows: F % 4 == 0 keeps rows 16-byte aligned
     bool vec4 = (g.F % 4 == 0) && (((uintptr_t)g.table | (uintptr_t)g.dst) % 16 == 0);
     const int C = vec4 ? g.F / 4 : g.F;
@@ -1270,6 +1285,7 @@ void launch_exchange_plan(hipStream_t s, const GatherArgs& g, int32_t me, int32_
     a.div_cap = FastDiv((uint32_t)(g.cache_capacity > 0 ? g.cache_capacity : 1));
     a.me = me; a.Kg = Kg; a.slot = slot; a.counts = counts; a.cursor = counts + kMaxParts;
     a.req_row = req_row; a.req_dst = req_dst;
+    LEGION_AUDIT_LAUNCH(s, "k_exch_count/k_exch_fill", LEGION_AW(slot), LEGION_AW(counts), LEGION_AW(req_row), LEGION_AW(req_dst), LEGION_AW(g.row_ptr), LEGION_AL(g.sampled_ids), LEGION_AL(g.nc), LEGION_AL(g.feat_map), LEGION_AL(g.shard_tab), LEGION_AR(g.table));
     HIP_CHECK(hipMemsetAsync(counts, 0, 2 * kMaxParts * sizeof(int32_t), s));
     const int64_t est = g.rows_hint > 0 ? std::min<int64_t>(rows_bound, (int64_t)g.rows_hint + g.rows_hint / 4 + 1024) : rows_bound;
     const int grid = grid_for(est, kBlock * 4, 64);
@@ -1287,6 +1303,7 @@ void launch_exchange_rows(hipStream_t s, bool scatter, const float* const* shard
     const int C = vec4 ? F / 4 : F;
     if ((int64_t)n * C >= (1ll << 31)) { LEGION_ARG_ERROR("legion_exchange: rows*F exceeds 2^31 work items"); return; }
     const FastDiv dc((uint32_t)C);
+    LEGION_AUDIT_LAUNCH(s, "k_exch_rows", LEGION_AW(out), LEGION_AL(shard_chunks), LEGION_AL(list), LEGION_AL(in));
     const int grid = grid_for((int64_t)n * C, kBlock * 2, 8192);
     if (scatter) {
         if (vec4) k_exch_rows<v4f, true><<<grid, kBlock, 0, s>>>(shard_chunks, chunk_shift, list, n, F, shard_pitch, in, out, dc, out_rows);
@@ -1301,6 +1318,7 @@ void launch_exchange_rows(hipStream_t s, bool scatter, const float* const* shard
 void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_t hops, unsigned long long* access,
                     int32_t* max_ids, int32_t bound)
 {
+    LEGION_AUDIT_LAUNCH(s, "k_hotness", LEGION_AW(access), LEGION_AW(max_ids), LEGION_AL(ids), LEGION_AL(nc));
     k_hotness<<<grid_for(bound, kBlock), kBlock, 0, s>>>(ids, nc, hops, access, max_ids);
     HIP_CHECK_LAST();
 }
@@ -1308,29 +1326,34 @@ void launch_hotness(hipStream_t s, const int32_t* ids, const int32_t* nc, int32_
 void launch_rng_probe(hipStream_t s, const int32_t* idx, const int32_t* deg, int32_t* k, int32_t n)
 {
     if (n <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_rng_probe", LEGION_AW(k), LEGION_AL(idx), LEGION_AL(deg));
     k_rng_probe<<<(n + 255) / 256, 256, 0, s>>>(idx, deg, k, n);
     HIP_CHECK_LAST();
 }
 
 void launch_aggregate_access(hipStream_t s, unsigned long long* agg, const unsigned long long* add, int32_t n)
 {
+    LEGION_AUDIT_LAUNCH(s, "k_aggregate_access", LEGION_AW(agg), LEGION_AR(add));
     k_aggregate_access<<<grid_for(n, 256), 256, 0, s>>>(agg, add, n);
     HIP_CHECK_LAST();
 }
 void launch_iota(hipStream_t s, int32_t* out, int32_t n)
 {
+    LEGION_AUDIT_LAUNCH(s, "k_iota", LEGION_AW(out));
     k_iota<<<grid_for(n, 256), 256, 0, s>>>(out, n);
     HIP_CHECK_LAST();
 }
 void launch_fill_i32(hipStream_t s, int32_t* p, int32_t v, int64_t n)
 {
     if (n <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_fill_i32", LEGION_AW(p));
     k_fill_i32<<<grid_for(n, 256), 256, 0, s>>>(p, v, n);
     HIP_CHECK_LAST();
 }
 void launch_fill_i8(hipStream_t s, int8_t* p, int8_t v, int64_t n)
 {
     if (n <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_fill_i8", LEGION_AW(p));
     k_fill_i8<<<grid_for(n, 256), 256, 0, s>>>(p, v, n);
     HIP_CHECK_LAST();
 }
@@ -1338,6 +1361,7 @@ void launch_build_feat_map(hipStream_t s, int32_t* feat_map, const int32_t* QF, 
 {
     launch_fill_i32(s, feat_map, -1, V);
     if (capacity <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_build_feat_map", LEGION_AW(feat_map), LEGION_AR(QF));
     k_build_feat_map<<<grid_for((int64_t)capacity * Kg, 256), 256, 0, s>>>(feat_map, QF, capacity, Kg, V);
     HIP_CHECK_LAST();
 }
@@ -1347,6 +1371,7 @@ void launch_build_topo_map(hipStream_t s, int8_t* owner, int32_t* row, const int
     launch_fill_i8(s, owner, (int8_t)-1, V);
     launch_fill_i32(s, row, -1, V);
     if (capacity <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_build_topo_map", LEGION_AW(owner), LEGION_AW(row), LEGION_AR(QT));
     k_build_topo_map<<<grid_for((int64_t)capacity * Kg, 256), 256, 0, s>>>(owner, row, QT, capacity, Kg, Ki, V);
     HIP_CHECK_LAST();
 }
@@ -1354,6 +1379,7 @@ void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, i
                          const float* table, const int32_t* QF, int32_t Kg, int32_t Ki, int32_t V)
 {
     if (rows <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_feat_fill_up", LEGION_AW(chunk), LEGION_AR(table), LEGION_AR(QF));
     k_feat_fill_up<<<grid_for((int64_t)rows * F, 256), 256, 0, s>>>(row0, rows, F, chunk_pitch > 0 ? chunk_pitch : F, table_pitch > 0 ? table_pitch : F,
                                                                   chunk, table, QF, Kg, Ki, V);
     HIP_CHECK_LAST();
@@ -1361,6 +1387,7 @@ void launch_feat_fill_up(hipStream_t s, int32_t row0, int32_t rows, int32_t F, i
 void launch_copy_rows_pitched(hipStream_t s, float* dst, int32_t dst_pitch, const float* src, int32_t src_pitch, int32_t F, int64_t rows)
 {
     if (rows <= 0 || F <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_copy_rows_pitched", LEGION_AW(dst), LEGION_AR(src));
     k_copy_rows_pitched<<<grid_for(rows * F, 256), 256, 0, s>>>(dst, dst_pitch, src, src_pitch, F, rows);
     HIP_CHECK_LAST();
 }
@@ -1368,6 +1395,7 @@ void launch_neighbor_count(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t
                            const int64_t* indptr, int64_t* count_out)
 {
     if (capacity <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_neighbor_count", LEGION_AW(count_out), LEGION_AR(QT), LEGION_AR(indptr));
     k_neighbor_count<<<grid_for(capacity, 256), 256, 0, s>>>(QT, Kg, Ki, capacity, V, indptr, count_out);
     HIP_CHECK_LAST();
 }
@@ -1376,22 +1404,26 @@ void launch_topo_fill_up(hipStream_t s, const int32_t* QT, int32_t Kg, int32_t K
                          int32_t* const* frag_chunks, int32_t edge_shift)
 {
     if (capacity <= 0) return;
+    LEGION_AUDIT_LAUNCH(s, "k_topo_fill_up", LEGION_AL(frag_indptr), LEGION_AL(frag_chunks), LEGION_AR(QT), LEGION_AR(indptr), LEGION_AR(indices));
     k_topo_fill_up<<<grid_for((int64_t)capacity * 64, 256), 256, 0, s>>>(QT, Kg, Ki, capacity, V, indptr, indices, frag_indptr, frag_chunks, edge_shift);
     HIP_CHECK_LAST();
 }
 void launch_chunk_ends(hipStream_t s, const int64_t* frag_indptr, int32_t capacity, int32_t edge_shift, int32_t nch, int64_t* ends)
 {
     if (nch <= 1) return;
+    LEGION_AUDIT_LAUNCH(s, "k_chunk_ends", LEGION_AW(ends), LEGION_AL(frag_indptr));
     k_chunk_ends<<<(nch + 63) / 64, 64, 0, s>>>(frag_indptr, capacity, edge_shift, nch, ends);
     HIP_CHECK_LAST();
 }
 void launch_edge_mem(hipStream_t s, const int32_t* order, uint64_t* edge_mem, int32_t V, const int64_t* indptr)
 {
+    LEGION_AUDIT_LAUNCH(s, "k_edge_mem", LEGION_AW(edge_mem), LEGION_AR(order), LEGION_AR(indptr));
     k_edge_mem<<<grid_for(V, 256), 256, 0, s>>>(order, edge_mem, V, indptr);
     HIP_CHECK_LAST();
 }
 void launch_topo_transactions(hipStream_t s, const int32_t* order, const uint64_t* hot, uint64_t* out, int32_t V, const int64_t* indptr)
 {
+    LEGION_AUDIT_LAUNCH(s, "k_topo_transactions", LEGION_AW(out), LEGION_AR(order), LEGION_AR(hot), LEGION_AR(indptr));
     k_topo_transactions<<<grid_for(V, 256), 256, 0, s>>>(order, hot, out, V, indptr);
     HIP_CHECK_LAST();
 }
@@ -1407,6 +1439,7 @@ void sort_by_hotness_desc(hipStream_t s, unsigned long long* keys, int32_t* ids,
     HIP_CHECK(hipMalloc(&keys_out, (size_t)n * sizeof(unsigned long long)));
     HIP_CHECK(hipMalloc(&ids_out, (size_t)n * sizeof(int32_t)));
     size_t tmp_bytes = 0;
+    LEGION_AUDIT_LAUNCH(s, "hipcub::DeviceRadixSort", LEGION_AW(keys), LEGION_AW(ids));
     HIP_CHECK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, keys, keys_out, ids, ids_out, n, 0, 64, s));
     void* tmp = nullptr;
     HIP_CHECK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
@@ -1424,6 +1457,7 @@ static void inclusive_scan_t(hipStream_t s, const T* in, T* out, int32_t n)
 {
     if (n <= 0) return;
     size_t tmp_bytes = 0;
+    LEGION_AUDIT_LAUNCH(s, "hipcub::DeviceScan", LEGION_AW(out), LEGION_AR(in));
     HIP_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, in, out, n, s));
     void* tmp = nullptr;
     HIP_CHECK(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));

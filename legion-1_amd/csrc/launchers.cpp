@@ -6,11 +6,14 @@
 #include <cstring>
 #include <iostream>
 
+#include "audit_hooks.h"
+
 using namespace legion;
 
 static inline int pool_dev(const GPUMemoryPool* p)
 {
     if (p->device_id >= 0) return p->device_id;
+    if (current_logical_device() >= 0) return current_logical_device();   // the logical GPU this thread selected (SetGPUDevice)
     int d = 0;
     (void)hipGetDevice(&d); // reference: dev_id = cudaGetDevice() (Kernels.cu:577-578)
     return d;
@@ -58,8 +61,17 @@ void batch_generator_kernel(void* strm_hdl, GPUNodeStorage* noder, GPUCache* cac
     if (all_labels == nullptr) { log_out() << "invalid label ptr\n"; return; }
 
     GPUMemoryPool* p = memorypool;
-    p->device_id = dev_id;
     const int q = p->current_pipe;
+    if (p->device_id != dev_id && audit::on()) {   // the pool starts serving this GPU: its scratch and its output buffers must live there
+        LEGION_AUDIT_OWNER(p->pos_map, dev_id, "batch_generator_kernel: scratch of the memory pool");
+        LEGION_AUDIT_OWNER(p->cand, dev_id, "batch_generator_kernel: scratch of the memory pool");
+        for (int i = 0; i < p->pipeline_depth; i++) {
+            LEGION_AUDIT_OWNER(p->sampled_ids[i], dev_id, "batch_generator_kernel: output buffers of the memory pool");
+            LEGION_AUDIT_OWNER(p->node_counter[i], dev_id, "batch_generator_kernel: output buffers of the memory pool");
+        }
+        LEGION_AUDIT_OWNER(all_ids, dev_id, "batch_generator_kernel: seed list");
+    }
+    p->device_id = dev_id;
     if (p->capturing) {
         // Recording a batch graph: cursor, epoch and the clamped size (Kernels.cu:224) are read / computed on the
         // device, `counter` is ignored, bounds are those of a full batch.

@@ -19,6 +19,8 @@
 
 #include <algorithm>
 
+#include "audit_hooks.h"
+
 using namespace legion;
 
 namespace {

@@ -12,11 +12,14 @@
 #include <fcntl.h>
 #include <fstream>
 #include <iostream>
+#include <optional>
 #include <sstream>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <thread>
 #include <unistd.h>
+
+#include "audit_hooks.h"
 
 using namespace legion;
 
@@ -48,9 +51,28 @@ struct Runner {
     bool gather_auto = true;
     bool pending = false;
     int pending_pipe = 0;
+    int64_t short_batches = 0;      // batches with more nodes than the feature buffers hold rows (see hand_over)
     hipEvent_t done_ev[LEGION_PIPELINE_DEPTH] = {};
     LegionBatchGraph* graphs[LEGION_PIPELINE_DEPTH][3] = {};
 };
+
+// Post a finished batch to its trainer.  The feature buffers hold a bounded number of rows (Runner_InitializeFeaturesBuffer: 1.2 x the
+// largest batch of the pre-sampling epoch, Server.cu:275); the gather never writes past them, so a batch that reached more nodes arrives
+// with its last rows missing and ipc_service.get_next refuses it (the reference's trainer reads past the allocation instead,
+// ipc_cuda_kernel.cu:200).  That is a trainer-side failure with no server-side trace -- so the server leaves one: the first such batch
+// is logged, all are counted (Runner_Finalize prints the total).
+static void hand_over(Runner* r, IPCEnv* env, int pipe)
+{
+    const int32_t rows = r->memorypool ? r->memorypool->feature_rows : 0;
+    const int32_t nodes = IPCEnv_MirroredNodeCounter(env, r->local_dev_id, pipe, 5 + 2 * r->hops);
+    if (rows > 0 && nodes > rows) {
+        if (r->short_batches++ == 0)
+            log_out() << r->local_dev_id << " Feature buffer too small: a batch has " << nodes << " nodes, the buffer holds " << rows
+                      << " rows -- the rows beyond it are not gathered and the trainer will refuse the batch (evaluation batches larger than "
+                         "the training batches of the pre-sampling epoch?)\n" << std::flush;
+    }
+    IPCEnv_IPCPost(env, r->local_dev_id, pipe);
+}
 
 extern "C" {
 
@@ -105,6 +127,9 @@ void Runner_Initialize(Runner* r, RunnerParams* params)
     GPUCache_InitializeCacheController(cache, r->local_dev_id, total_num_nodes);
     r->memorypool = NewGPUMemoryPool(r->pipeline_depth);
     GPUMemoryPool_AllocateScratch(r->memorypool, total_num_nodes, batch_size, params->fanout, hop_num);
+    LEGION_AUDIT_OWNER(r->memorypool->pos_map, r->local_dev_id, "Runner_Initialize: scratch of the memory pool");
+    LEGION_AUDIT_STREAM(r->streams[0], r->local_dev_id, "Runner_Initialize: sampler stream");
+    LEGION_AUDIT_STREAM(r->streams[1], r->local_dev_id, "Runner_Initialize: gather stream");
     r->memorypool->device_id = r->local_dev_id;
     r->num_ids = GPUMemoryPool_NumIds(r->memorypool);
     r->float_attr_len = GPUNodeStorage_GetFloatAttrLen(noder);
@@ -225,7 +250,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
         const auto spin = std::chrono::microseconds(IPCEnv_HandoffSpinUs());
         while (IPCEnv_IPCTryWait(env, r->local_dev_id, r->current_pipe, 0) != 0) {
             if (hipEventQuery(r->done_ev[r->pending_pipe]) == hipSuccess) {
-                IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+                hand_over(r, env, r->pending_pipe);
                 r->pending = false;
                 IPCEnv_IPCWait(env, r->local_dev_id, r->current_pipe);
                 break;
@@ -243,7 +268,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     auto post_poisoned = [&]() {
         if (r->pending) {
             (void)hipEventSynchronize(r->done_ev[r->pending_pipe]);
-            IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+            hand_over(r, env, r->pending_pipe);
             r->pending = false;
         }
         (void)hipDeviceSynchronize();
@@ -316,7 +341,7 @@ void Runner_RunOnce(Runner* r, RunnerParams* params)
     }
     if (r->pending) { // batch i is queued: now hand batch i-1 to its trainer
         HIP_CHECK(hipEventSynchronize(r->done_ev[r->pending_pipe]));
-        IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+        hand_over(r, env, r->pending_pipe);
     }
     r->pending = true;
     r->pending_pipe = r->current_pipe;
@@ -331,14 +356,17 @@ void Runner_Finalize(Runner* r, RunnerParams* params)
     DeviceGuard guard(r->local_dev_id);
     if (r->pending) { // the last batch of the pipelined loop
         HIP_CHECK(hipEventSynchronize(r->done_ev[r->pending_pipe]));
-        IPCEnv_IPCPost(env, r->local_dev_id, r->pending_pipe);
+        hand_over(r, env, r->pending_pipe);
         r->pending = false;
     }
+    if (r->short_batches > 0)
+        log_out() << r->local_dev_id << " Feature buffer too small for " << r->short_batches << " batches (see the first message)\n" << std::flush;
     IPCEnv_IPCWait(env, r->local_dev_id, (r->current_pipe + 1) % r->pipeline_depth);
     GPUMemoryPool_Finalize(r->memorypool);
 }
 
 GPUMemoryPool* Runner_GetMemoryPool(Runner* r) { return r ? r->memorypool : nullptr; }
+int64_t Runner_ShortBatches(const Runner* r) { return r ? r->short_batches : 0; }
 
 void Runner_Delete(Runner* r)
 {
@@ -536,6 +564,9 @@ void Server_Initialize(Server* s, int global_shard_count)
             return;
         }
     }
+    // from the first device call on the main thread works on GPU 0 unless a scope below says otherwise (the reference's main thread never
+    // leaves device 0); not before the meta line and the synth: source are validated -- a refused configuration touches no device
+    std::optional<DeviceGuard> boot;
     const int32_t V = m.node_num;
     const int32_t F = m.float_attr_len;
     std::vector<int32_t> training_ids, validation_ids, testing_ids, all_labels, partition_index;
@@ -548,6 +579,7 @@ void Server_Initialize(Server* s, int global_shard_count)
         // shape.  V, E, F of the meta line must be the generator's (E = 0: not checked); the seed-set sizes of the meta line take
         // the first n ids of the generator's train / valid / test ranges.
         if (!load_synth(s, G, spec)) return;
+        boot.emplace(0);
         training_ids.resize(m.training_set_num); validation_ids.resize(m.validation_set_num); testing_ids.resize(m.testing_set_num);
         for (int32_t i = 0; i < m.training_set_num; i++) training_ids[i] = legion_synth_seed_id_host(i, V, spec.M2, spec.C2);
         for (int32_t i = 0; i < m.validation_set_num; i++) validation_ids[i] = legion_synth_seed_id_host((int64_t)spec.n_train + i, V, spec.M2, spec.C2);
@@ -558,6 +590,7 @@ void Server_Initialize(Server* s, int global_shard_count)
         }
     } else {
     // Load_Graph / Load_Feature (GPUGraphStore.cu:254-325): pinned, device-mapped host memory
+    boot.emplace(0);
     log_out() << "Start load graph\n";
     s->indptr = (int64_t*)host_alloc_space64(((int64_t)V + 1) * 8);
     s->indices = (int32_t*)host_alloc_space64(m.edge_num * 4);
@@ -685,10 +718,14 @@ void Server_Initialize(Server* s, int global_shard_count)
                 const int phys = physical_device(i);
                 int src = -1;
                 for (int j = 1; j < i; j++) if (physical_device(j) == phys && s->graph->replica_indptr[j]) src = j;
-                if (phys == have[0]) continue;                         // shares GPU 0's tables
+                if (phys == have[0]) {                                 // shares GPU 0's tables
+                    LEGION_AUDIT_SHARE(s->indptr, i); LEGION_AUDIT_SHARE(s->indices, i); LEGION_AUDIT_SHARE(s->feats, i);
+                    continue;
+                }
                 if (src >= 0) {
                     s->graph->replica_indptr[i] = s->graph->replica_indptr[src]; s->graph->replica_indices[i] = s->graph->replica_indices[src];
                     s->noder->replica_attrs[i] = s->noder->replica_attrs[src];
+                    LEGION_AUDIT_SHARE(s->graph->replica_indptr[i], i); LEGION_AUDIT_SHARE(s->graph->replica_indices[i], i); LEGION_AUDIT_SHARE(s->noder->replica_attrs[i], i);
                     continue;
                 }
                 DeviceGuard guard(i);
@@ -739,6 +776,7 @@ void Server_Initialize(Server* s, int global_shard_count)
 // PreSc, Server.cu:83-114
 void Server_PreSc(Server* s, int cache_agg_mode)
 {
+    DeviceGuard boot(0);
     auto t1 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (int i = 0; i < s->shard_count; i++)
@@ -777,6 +815,7 @@ void Server_Run(Server* s)
 // Finalize, Server.cu:137-146
 void Server_Finalize(Server* s)
 {
+    DeviceGuard boot(0);
     for (int i = 0; i < s->shard_count; i++) {
         int64_t st[3];
         legion_peer_exchange_stats(Runner_GetMemoryPool(s->runners[i]), st);     // $LEGION_PEER_GATHER=exchange: what the bulk-copy gather did
@@ -786,12 +825,15 @@ void Server_Finalize(Server* s)
     GPUGraphStorage_Finalize(s->graph);
     GPUNodeStorage_Finalize(s->noder);
     IPCEnv_Finalize(s->env);
+    log_out() << std::flush;
+    (void)legion_audit_report();     // $LEGION_DEVICE_AUDIT=1: what the logical-device audit saw (server_main exits non-zero on a violation)
     log_out() << "Server Stopped\n";
 }
 
 void Server_Delete(Server* s)
 {
     if (!s) return;
+    DeviceGuard boot(0);
     for (auto r : s->runners) Runner_Delete(r);
     for (auto p : s->params) delete p;
     if (s->cache) GPUCache_Delete(s->cache);

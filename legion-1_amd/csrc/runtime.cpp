@@ -5,6 +5,8 @@
 #include <cstring>
 #include <mutex>
 
+#include "audit_hooks.h"
+
 namespace legion {
 
 static int g_error_mode = LEGION_ERR_EXIT;
@@ -82,10 +84,13 @@ DeviceGuard::DeviceGuard(int logical)
     int want = physical_device(logical);
     if (want != prev) HIP_CHECK(hipSetDevice(want));
     else prev = -1;
+    prev_logical = current_logical_device();
+    set_current_logical_device(logical);
 }
 DeviceGuard::~DeviceGuard()
 {
     if (prev >= 0) (void)hipSetDevice(prev);
+    set_current_logical_device(prev_logical);
 }
 
 } // namespace legion
@@ -137,7 +142,11 @@ void d_copy_2_h(void* h_ptr, void* d_ptr, unsigned int num_bytes)
     HIP_CHECK(hipMemcpy(h_ptr, d_ptr, num_bytes, hipMemcpyDeviceToHost));
 }
 void d_free_space(void* d_ptr) { (void)hipFree(d_ptr); }
-void SetGPUDevice(int32_t shard_id) { HIP_CHECK(hipSetDevice(physical_device(shard_id))); }
+void SetGPUDevice(int32_t shard_id)
+{
+    HIP_CHECK(hipSetDevice(physical_device(shard_id)));
+    set_current_logical_device(shard_id);
+}
 int32_t GetGPUDevice(void)
 {
     int dev = 0;

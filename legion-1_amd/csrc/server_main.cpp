@@ -32,5 +32,7 @@ int main(int argc, char** argv)
     Server_Run(server);
     Server_Finalize(server);
     Server_Delete(server);
-    return 0;
+    int64_t audit[4] = {0, 0, 0, 0};
+    legion_audit_counts(audit);
+    return audit[1] > 0 ? 4 : 0;     // $LEGION_DEVICE_AUDIT=1: a wrong-device violation (listed by Server_Finalize) fails the run
 }

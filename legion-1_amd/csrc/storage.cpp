@@ -6,6 +6,8 @@
 #include <cstring>
 #include <set>
 
+#include "audit_hooks.h"
+
 using namespace legion;
 
 // all-pairs peer access between the physical devices behind the logical GPUs
@@ -14,6 +16,8 @@ static void enable_p2p(int32_t partition_count)
 {
     std::set<int> phys;
     for (int i = 0; i < partition_count; i++) phys.insert(physical_device(i));
+    // the audit's view: on a node every logical GPU is a device of its own and this loop enables every pair
+    if (audit::on()) for (int a = 0; a < partition_count; a++) for (int b = 0; b < partition_count; b++) if (a != b) audit::record_peer(a, b);
     if (phys.size() < 2) return;
     int cur = 0;
     HIP_CHECK(hipGetDevice(&cur));
@@ -62,6 +66,7 @@ static void replicate_table(const T* src, int64_t count, int32_t P, std::vector<
             if (have) HIP_CHECK(hipMemcpy(have, src, (size_t)count * sizeof(T), hipMemcpyDefault));
             per_phys.emplace_back(phys, have);
         }
+        LEGION_AUDIT_SHARE(have, p);     // logical GPUs of one physical device share its replica
         replica[p] = have;
     }
 }
@@ -148,6 +153,7 @@ static void publish_fragment_tables(GPUGraphStorage* g)
             for (size_t q = 0; q < g->frag[p].ix.size(); q++) h[(size_t)P * ip_nch + (size_t)p * ix_nch + q] = g->frag[p].ix[q];
         }
         DeviceGuard guard(dev);
+        LEGION_AUDIT_TABLE(dev, h.data(), h.size(), "fragment chunk table");
         if (g->d_frag_tab[dev] && (regrow || !any)) { HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(g->d_frag_tab[dev]); g->d_frag_tab[dev] = nullptr; }
         if (!any) continue;
         if (!g->d_frag_tab[dev]) HIP_CHECK(hipMalloc(&g->d_frag_tab[dev], h.size() * sizeof(void*)));
@@ -215,6 +221,8 @@ void GPUGraphStorage_GraphCache(GPUGraphStorage* g, int32_t* QT, int32_t Ki, int
         HIP_CHECK(hipDeviceSynchronize());
         HIP_CHECK(hipFree(d_chunks));
         if (d_index) HIP_CHECK(hipFree(d_index));
+        for (auto* q : f.ip) LEGION_AUDIT_OWNER(q, dev, "GraphCache: indptr chunk of a fragment");
+        for (auto* q : f.ix) LEGION_AUDIT_OWNER(q, dev, "GraphCache: indices chunk of a fragment");
         f.complete = true;
     }
     // every clique member sees every clique fragment (pointer tables copied D2D in the reference, :128-131)
@@ -398,6 +406,7 @@ void GPUNodeStorage_Build(GPUNodeStorage* n, const LegionBuildInfo* info)
             n->testing_set_ids[p] = upload_i32(info->testing_set_ids[p], info->testing_set_num[p]);
             n->testing_labels[p] = upload_i32(info->testing_labels[p], info->testing_set_num[p]);
         }
+        LEGION_AUDIT_OWNER(n->training_set_ids[p], p, "GPUNodeStorage_Build: seed list");
     }
 }
 
@@ -428,6 +437,7 @@ int64_t GPUNodeStorage_ReplicateToDevices(GPUNodeStorage* n)
             }
             per_phys.emplace_back(phys, have);
         }
+        LEGION_AUDIT_SHARE(have, p);
         n->replica_attrs[p] = have;
     }
     return V * pitch * 4;
@@ -555,6 +565,7 @@ int32_t* GPUMemoryPool_GetCacheSearchBuffer(const GPUMemoryPool* p) { return p->
 char* GPUMemoryPool_GetTmpPartIdx(const GPUMemoryPool* p) { return (char*)p->tmp_part_ind; }
 int32_t* GPUMemoryPool_GetTmpPartOff(const GPUMemoryPool* p) { return p->tmp_part_off; }
 uint64_t* GPUMemoryPool_GetPositionMap(const GPUMemoryPool* p) { return (uint64_t*)p->pos_map; }
+int32_t* GPUMemoryPool_GetCandidateBuffer(const GPUMemoryPool* p) { return p->cand; }
 uint32_t GPUMemoryPool_GetBatchSerial(const GPUMemoryPool* p) { return p->batch_serial; }
 void GPUMemoryPool_SetBatchSerial(GPUMemoryPool* p, uint32_t serial) { p->batch_serial = serial; p->ctl_synced = false; }
 

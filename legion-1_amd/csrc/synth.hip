@@ -6,6 +6,8 @@
 #include <cmath>
 #include <cstring>
 
+#include "audit_hooks.h"
+
 namespace legion {
 
 __host__ __device__ inline uint64_t sm64(uint64_t z)
@@ -127,6 +129,36 @@ __global__ __launch_bounds__(256) void k_copy_f4(copy_v4f* __restrict__ dst, con
     }
 }
 
+// What a trainer's READ of a served batch costs, without a model (bench.py's reading consumer): legion_graphsage.py:72-89 reads every
+// feature row and both COO arrays of the batch before it hands the pipe back.  Every 32-bit word of [src, src + 16 * n16) -- plus n_tail
+// trailing words -- is added into *acc (u64, wrap-around): exact and order-independent, so the sum doubles as a checksum of what was read.
+// Four non-temporal 16-byte loads in flight per lane, one atomic per workgroup.
+typedef unsigned int sum_v4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_sum_words(const sum_v4u* __restrict__ src, int64_t n16, const uint32_t* __restrict__ tail, int32_t n_tail,
+                                                   unsigned long long* __restrict__ acc)
+{
+    __shared__ unsigned long long s_part[4];
+    unsigned long long sum = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        sum_v4u v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; u++) sum += (unsigned long long)v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    for (; i < n16; i += stride) {
+        const sum_v4u v = __builtin_nontemporal_load(src + i);
+        sum += (unsigned long long)v.x + v.y + v.z + v.w;
+    }
+    if (blockIdx.x == 0 && (int32_t)threadIdx.x < n_tail) sum += tail[threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+
 } // namespace legion
 
 using namespace legion;
@@ -145,6 +177,7 @@ void legion_synth_degrees(void* stream, int64_t* deg_out, int32_t v0, int32_t n,
     if (n <= 0) return;
     Ladder lad;
     for (int i = 0; i < NBUCKET + 2; i++) lad.lo[i] = ladder_host26[i];
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_synth_degrees", LEGION_AW(deg_out));
     k_synth_degrees<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(deg_out, v0, n, lad);
     HIP_CHECK_LAST();
 }
@@ -152,6 +185,7 @@ void legion_synth_neighbors_skew(void* stream, int32_t* indices_out, int64_t e0,
                                  int32_t skew_of_256)
 {
     if (n <= 0) return;
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_synth_neighbors", LEGION_AW(indices_out));
     k_synth_neighbors<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(indices_out, e0, n, (uint32_t)V, M, C, (uint32_t)skew_of_256);
     HIP_CHECK_LAST();
 }
@@ -164,6 +198,7 @@ void legion_synth_lp_seeds(void* stream, int32_t* out, const int32_t* srcs, cons
 {
     if (n_triples <= 0) return;
     if (batch_size < 3 || batch_size % 3) { LEGION_ARG_ERROR("legion_synth_lp_seeds: batch size must be a multiple of 3"); return; }
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_synth_lp_seeds", LEGION_AW(out), LEGION_AL(srcs), LEGION_AL(triple_no), LEGION_AR(indptr), LEGION_AR(indices));
     k_synth_lp_seeds<<<big_grid(n_triples), 256, 0, (hipStream_t)stream>>>(out, srcs, triple_no, n_triples, batch_size, indptr, indices,
                                                                            (uint32_t)V, seed);
     HIP_CHECK_LAST();
@@ -171,6 +206,7 @@ void legion_synth_lp_seeds(void* stream, int32_t* out, const int32_t* srcs, cons
 void legion_synth_features(void* stream, float* out, int64_t v0, int64_t nrows, int32_t F)
 {
     if (nrows <= 0) return;
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_synth_features", LEGION_AW(out));
     k_synth_features<<<big_grid(nrows * F), 256, 0, (hipStream_t)stream>>>(out, v0, nrows, F, F);
     HIP_CHECK_LAST();
 }
@@ -178,12 +214,14 @@ void legion_synth_features_pitched(void* stream, float* out, int64_t v0, int64_t
 {
     if (nrows <= 0) return;
     if (pitch < F) { LEGION_ARG_ERROR("legion_synth_features_pitched: pitch < F"); return; }
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_synth_features", LEGION_AW(out));
     k_synth_features<<<big_grid(nrows * F), 256, 0, (hipStream_t)stream>>>(out, v0, nrows, F, pitch);
     HIP_CHECK_LAST();
 }
 void legion_synth_labels(void* stream, int32_t* out, int32_t v0, int32_t n, int32_t classes)
 {
     if (n <= 0) return;
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_synth_labels", LEGION_AW(out));
     k_synth_labels<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(out, v0, n, classes);
     HIP_CHECK_LAST();
 }
@@ -265,6 +303,7 @@ void legion_synth_seed_ids(void* stream, int32_t* out, int64_t i0, int64_t n, in
                            int32_t stride, int32_t phase)
 {
     if (n <= 0) return;
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_synth_seed_ids", LEGION_AW(out));
     k_synth_seed_ids<<<big_grid(n), 256, 0, (hipStream_t)stream>>>(out, i0, n, (uint32_t)V, M2, C2, stride, phase);
     HIP_CHECK_LAST();
 }
@@ -277,6 +316,7 @@ int legion_copy_f4_cfg(void* stream, void* dst, const void* src, int64_t bytes, 
     hipStream_t s = (hipStream_t)stream;
     copy_v4f* d = (copy_v4f*)dst;
     const copy_v4f* r = (const copy_v4f*)src;
+    LEGION_AUDIT_LAUNCH(s, "k_copy_f4", LEGION_AW(dst), LEGION_AR(src));
 #define LEGION_COPY_CASE(U, N, C) if (unroll == U && nt == N && contig == C) { k_copy_f4<U, N, (C != 0)><<<grid, 256, 0, s>>>(d, r, n); HIP_CHECK_LAST(); return 0; }
 #define LEGION_COPY_NT(U, C) LEGION_COPY_CASE(U, 0, C) LEGION_COPY_CASE(U, 1, C) LEGION_COPY_CASE(U, 2, C) LEGION_COPY_CASE(U, 3, C)
     LEGION_COPY_NT(1, 0) LEGION_COPY_NT(2, 0) LEGION_COPY_NT(4, 0) LEGION_COPY_NT(8, 0)
@@ -285,6 +325,18 @@ int legion_copy_f4_cfg(void* stream, void* dst, const void* src, int64_t bytes, 
 #undef LEGION_COPY_CASE
     LEGION_ARG_ERROR("legion_copy_f4_cfg: no such variant");
     return -1;
+}
+// *acc += the sum of the 32-bit words of [src, src + bytes); src 16-byte aligned, bytes a multiple of 4
+void legion_sum_words(void* stream, const void* src, int64_t bytes, uint64_t* acc)
+{
+    if (bytes <= 0) return;
+    if (!src || !acc || ((uintptr_t)src & 15) || (bytes & 3)) { LEGION_ARG_ERROR("legion_sum_words: src must be 16-byte aligned, bytes a multiple of 4"); return; }
+    const int64_t n16 = bytes / 16;
+    const int32_t n_tail = (int32_t)((bytes - n16 * 16) / 4);
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>((n16 + 1023) / 1024, 1), 2048);
+    LEGION_AUDIT_LAUNCH((hipStream_t)stream, "k_sum_words", LEGION_AW(acc), LEGION_AR(src));
+    k_sum_words<<<grid, 256, 0, (hipStream_t)stream>>>((const sum_v4u*)src, n16, (const uint32_t*)src + n16 * 4, n_tail, (unsigned long long*)acc);
+    HIP_CHECK_LAST();
 }
 void legion_copy_f4(void* stream, void* dst, const void* src, int64_t bytes)
 {

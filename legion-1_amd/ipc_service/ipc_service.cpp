@@ -9,6 +9,7 @@
 #include <torch/extension.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,10 @@ static LegionIPCClient* env = nullptr;
 static int32_t h_node_counter[16];
 static int32_t h_edge_counter[16];
 static int32_t g_hops = 2;
+// ONE consumer thread per process is the contract (the reference's trainer loop, legion_graphsage.py:72-89):
+// get_next / synchronize run without the GIL and share `env`, the two counter arrays and the client's current pipe, so the entry points
+// are serialised by this lock -- uncontended in the reference's loop, and a second Python thread gets whole counters instead of torn ones.
+static std::mutex g_mu;
 
 static void require_env()
 {
@@ -39,6 +44,7 @@ void FinalizeIPC()
 
 std::vector<torch::Tensor> get_next(int feature_dim)
 {
+    std::lock_guard<std::mutex> lock(g_mu);
     require_env();
     legion_ipc_client_wait(env); // env->Wait(), ipc_service.cpp:42
     legion_ipc_client_read_counters(env, h_node_counter, h_edge_counter);
@@ -55,6 +61,8 @@ std::vector<torch::Tensor> get_next(int feature_dim)
     const int64_t rows = legion_ipc_client_feature_rows(env);
     TORCH_CHECK(rows <= 0 || n_nodes <= rows, "ipc_service: the batch has ", n_nodes, " nodes but the server's feature buffer holds ", rows,
                 " rows (sized from the pre-sampling epoch; use a training batch size >= the validation / test batch size)");
+    for (int w = 0; w <= 4; w++)    // legion_ipc_client_open refuses a server that has not registered its buffers; never build a tensor on a null one
+        TORCH_CHECK(legion_ipc_client_buffer(env, w) != nullptr, "ipc_service: hand-off buffer ", w, " of this GPU was never registered by the server");
     std::vector<torch::Tensor> out;
     out.push_back(torch::from_blob(legion_ipc_client_buffer(env, 0), {n_nodes}, i32));
     out.push_back(torch::from_blob(legion_ipc_client_buffer(env, 1), {n_nodes, (int64_t)feature_dim}, f32));
@@ -71,6 +79,7 @@ std::vector<torch::Tensor> get_next(int feature_dim)
 // (ipc_service.cpp:60-72)
 std::vector<int> get_block_size()
 {
+    std::lock_guard<std::mutex> lock(g_mu);
     std::vector<int> ret;
     const int H = g_hops;
     for (int k = 1; k <= H; k++) {
@@ -90,6 +99,7 @@ std::vector<int32_t> get_steps()
 
 void Synchronize()
 {
+    std::lock_guard<std::mutex> lock(g_mu);
     require_env();
     // env->Post(), ipc_service.cpp:83-85.  legion_ipc_client_post waits for the device first: the reference trainers call this with
     // their optimizer step still queued (legion_graphsage.py:93-116), and a posted pipe is overwritten by the server

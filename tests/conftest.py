@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Every GPU test runs under the logical-device audit (csrc/audit.h): the library of this process AND every child it starts (the
+# `legion` server, bench.py, the trainer-side clients) tag their streams / events / allocations with the logical GPU they were
+# created under and check every launch, copy, event and pointer table against it.  A violation is a sticky error (K.check() raises),
+# fails the `legion` binary (exit code 4) and fails the test through the fixture below.  LEGION_DEVICE_AUDIT=0 switches it off.
+os.environ.setdefault("LEGION_DEVICE_AUDIT", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -43,6 +49,30 @@ def assert_batch_equal(ref, got, keys=BATCH_KEYS):
         if not np.array_equal(a, b):
             bad = np.nonzero(a.reshape(-1) != b.reshape(-1))[0]
             raise AssertionError(f"{k}: {len(bad)} mismatches, first at {bad[:5]}: {a.reshape(-1)[bad[:5]]} vs {b.reshape(-1)[bad[:5]]}")
+
+
+@pytest.fixture(autouse=True)
+def _no_device_audit_violation(request):
+    """After every test: the library of THIS process must not have recorded a wrong-device violation (tests that provoke one
+    reset the audit themselves).  Before every test: the thread is back on logical GPU 0, wherever the previous test left it."""
+    if request.node.get_closest_marker("gpu") is None:      # no device behind a CPU test
+        yield
+        return
+    capi = sys.modules.get("legion1_amd.capi")
+    if capi is not None and capi._lib is not None and capi._lib.legion_audit_enabled():
+        capi._lib.SetGPUDevice(0)
+    yield
+    capi = sys.modules.get("legion1_amd.capi")
+    if capi is None or capi._lib is None or not capi._lib.legion_audit_enabled():
+        return
+    import ctypes
+    c = (ctypes.c_int64 * 4)()
+    capi._lib.legion_audit_counts(c)
+    if c[1]:
+        msgs = [capi._lib.legion_audit_message(i).decode() for i in range(min(5, capi._lib.legion_audit_message_count()))]
+        capi._lib.legion_audit_reset()
+        capi._lib.legion_clear_error()
+        raise AssertionError("device audit: %d violation(s): %s" % (c[1], " | ".join(msgs)))
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,7 @@
 """Trainer-side process of the poisoned-pipe test: attaches through `ipc_service` and consumes batches.  The server fails
 that batch and posts the pipe with every node-counter word at -1 (runner.cpp, post_poisoned): get_next must raise, not hand
-out tensors with negative or stale sizes.  usage: ipc_client_poison.py <feature_dim>; exit 0 = raised as specified."""
+out tensors with negative or stale sizes.  usage: ipc_client_poison.py <feature_dim> [expected error text]; exit 0 = raised as
+specified (default text: "sampling server failed") after exactly one good batch."""
 import os
 import sys
 
@@ -24,5 +25,6 @@ try:
 except RuntimeError as e:
     print("RAISED after %d good batches:" % good, str(e).splitlines()[0], flush=True)
     ipc_service.finalize()
-    sys.exit(0 if ("sampling server failed" in str(e) and good == 1) else 5)
+    want = sys.argv[2] if len(sys.argv) > 2 else "sampling server failed"
+    sys.exit(0 if (want in str(e) and good == 1) else 5)
 sys.exit(7)

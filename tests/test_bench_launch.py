@@ -227,7 +227,8 @@ def test_extra_leg_plan():
         c = C()
         c.world, c.args = world, bench.parse(list(flags))
         return bench.extra_leg_names(c)
-    assert names(1) == ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]     # legs that re-use the headline graph first
+    assert names(1) == ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr",
+                        "partitioned_csr_host_spill"]     # legs that re-use the headline graph first; the 137 GB pinned-host table last
     assert names(8) == ["lp", "uk_union", "served_all"] and names(2) == ["lp", "uk_union", "served_all"]    # r03 keys + (round 5, last) the one-server-process deployment
     assert names(1, "--extra-legs", "none") == [] and names(8, "--extra-legs", "none") == []
     assert names(1, "--workload", "products") == [] and names(1, "--task", "lp") == [] and names(1, "--headline-only") == []   # auto: default workload only

@@ -50,6 +50,13 @@ def test_two_rank_line_has_every_leg():
     assert list(line["extra_legs"]) == ["lp", "uk_union", "served_all"]
     assert sa.get("error") is None and sa["n_gpus"] == 2 and sa["value"] > 0 and len(sa["ms_per_step_per_gpu"]) == 2 and sa["shared_device"] is True, sa
     assert sa["gpu0_batches_equal_rank0s_timed_ones"] is True and "REHEARSAL" in sa["what"] and len(sa["server_gather"]) == 2
+    if os.environ.get("LEGION_DEVICE_AUDIT") == "1":
+        # the whole two-rank command -- replicated headline, unified-cache leg with in-kernel peer reads and the exchange
+        # variant, config 4 / 5 legs, and ONE server over two logical GPUs with two consumers -- under the logical-device audit: rank 0's library
+        # and the served_all server checked thousands of launches / copies / events / tables against their logical GPU and found nothing
+        da, sda = line["device_audit"], sa["server_device_audit"]
+        assert da["violations"] == 0 and da["checks"] > 1000, da
+        assert sda["violations"] == 0 and sda["unattributed"] == 0 and sda["checks"] > 1000, sda
 
 
 def test_a_failed_leg_is_named_and_the_other_legs_survive():
@@ -91,7 +98,7 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     assert r.returncode == 0, r.stderr[-3000:]
     assert line["n_gpus"] == 1 and line["legs_failed"] == [] and line["value"] > 0 and line["cpu_baseline"]["value"] > 0
     legs = line["extra_legs"]
-    assert list(legs) == ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr"]
+    assert list(legs) == ["served", "lp", "cached_gather", "products_2hop", "products_3hop", "partitioned_csr", "partitioned_csr_host_spill"]
     sv = legs.pop("served")
     # the server binary (dataset source synth:papers100M:0.02) + a consumer process, as fresh children of the bench
     assert sv.get("error") is None and sv["value"] > 0 and sv["ms_per_step"] > 0 and sv["windows"] >= 1, sv
@@ -99,6 +106,16 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     assert sv["served_batches_equal_the_timed_ones"] is True and sv["server_tables"] == "generated in HBM"
     assert sv["ratio_to_alt_schedule_levels"] > 0 and sv["fanout"] == [25, 10, 5] and sv["F"] == 128
     assert line["value_served"] == sv["value"] and line["ms_per_step_served"] == sv["ms_per_step"]        # also at the top level, next to value / value_overlap
+    # value_served is the figure of a consumer that READS what it is served -- every feature row and both COO arrays, on its own
+    # stream, before the pipe goes back -- with one batch's sums checked (features against the generator's closed form of the rows the batch names);
+    # the null consumer (the hand-off alone) sits beside it
+    rc = sv["reading_consumer"]
+    assert sv["consumer"] == "reading" and rc["read_GB_per_batch"] > 0 and rc["consumer_read_GBps"] > 0
+    ck = rc["checksum"]
+    assert ck["features_equal_the_generators_rows"] is True and ck["coo_src_equal_host_copy"] is True and ck["coo_dst_equal_host_copy"] is True and ck["rows"] > 0, ck
+    nul = sv["null_consumer"]
+    assert nul.get("error") is None and nul["value"] > 0 and nul["served_batches_equal_the_timed_ones"] is True and sv["ratio_to_null_consumer"] > 0
+    assert line["value_served_null"] == nul["value"] and line["ms_per_step_served_null"] == nul["ms_per_step"]
     for name, leg in legs.items():
         assert leg.get("error") is None and leg["value"] > 0 and leg["ms_per_step"] > 0, (name, leg)
         assert 0 < leg["gather_frac_of_hbm_peak"] < 1 and leg["sampler_us_per_batch"] > 0 and 0 < leg["pipeline_frac"] < 1, (name, leg)
@@ -119,6 +136,11 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     assert pc["F"] == 256 and pc["fanout"] == [25, 10] and pc["topo_rows_per_gpu"] > 0 and pc["Kg"] == 1
     sr = pc["served_replicated"]     # config 4's shape through the server (replicated: the uk-union tables fit one GPU's HBM)
     assert sr.get("error") is None and sr["value"] > 0 and sr["F"] == 256 and sr["served_batches_equal_the_timed_ones"] is None and sr["schedule"]["train_steps"] > 0
+    # config 4 as BASELINE states it -- the feature table in pinned host memory behind the 10 % HBM cache, misses over PCIe
+    hs = legs["partitioned_csr_host_spill"]
+    assert hs["F"] == 256 and hs["fanout"] == [25, 10] and hs["topo_rows_per_gpu"] > 0 and "PINNED HOST" in hs["what"]
+    sp = hs["host_spill"]
+    assert 0 < sp["hit_rate"] < 1 and sp["miss_rows_last_batch"] > 0 and 0 < sp["pcie_read_GBps"] < 2 * sp["pcie_peak_GBps"], sp
 
 
 def test_a_symmetric_exchange_failure_does_not_cost_the_rest_of_the_line():

@@ -18,6 +18,19 @@ pytestmark = pytest.mark.gpu
 SERVER = os.path.join(ROOT, "legion-1_amd", "csrc", "legion")
 
 
+def _audit_clean(log_text, gpus=1):
+    """$LEGION_DEVICE_AUDIT=1 (tests/conftest.py): the server's summary line -- checks ran, none failed, and the server attributed every stream,
+    allocation and launch to a logical GPU (returns the parsed counts; None when the audit is off)."""
+    import re
+    if os.environ.get("LEGION_DEVICE_AUDIT") != "1":
+        return None
+    m = re.search(r"Device audit: (\d+) checks, (\d+) violations, (\d+) unattributed, (\d+) launches with peer arguments", log_text)
+    assert m, log_text[-1500:]
+    checks, bad, unattributed, peer = (int(x) for x in m.groups())
+    assert checks > 100 * gpus and bad == 0 and unattributed == 0, (m.group(0), log_text[-1500:])
+    return dict(checks=checks, violations=bad, unattributed=unattributed, peer_launches=peer)
+
+
 def _wait_ready(proc, log_path, timeout=240):
     t0 = time.time()
     while time.time() - t0 < timeout:
@@ -351,6 +364,8 @@ def test_two_gpu_server_unified_cache_two_trainers(tmp_path, synth, oracle, peer
     steps, tb, vb, sb = oracle.coordinate([len(p) for p in parts[0]], [len(p) for p in parts[1]], [len(p) for p in parts[2]], B)
     text = open(log).read()
     assert "xGMI Clique: 1 GPU Per Clique: 2" in text and "Feat capacity" in text   # the cost model sized a real cache
+    audit = _audit_clean(text, G)     # two runner threads, shards + fragments on their owners, peer reads / bulk copies between them: clean
+    assert audit is None or audit["peer_launches"] > 0, audit     # ... and the cached gathers / fill-ups really read a peer's memory
     assert ("peer exchange gather:" in text) == (peer_gather == "exchange"), text[-1500:]
     H = len(fan)
     for g in range(G):
@@ -476,6 +491,7 @@ def _serve(tmp_path, spec, meta_line, fan, G, agg_mode, epochs, extra_env=None, 
                 c.kill()
         if server.poll() is None:
             server.kill()
+    _audit_clean(open(log).read(), G)
     return [json.load(open(out)) for out, _ in clients], open(log).read()
 
 

@@ -471,6 +471,71 @@ def test_poisoned_pipe_reaches_the_trainer_as_an_error(K, small_ds, tmp_path):
     assert rc == 0 and "RAISED after 1 good batches" in text and "sampling server failed" in text, text[-3000:]
 
 
+def test_a_batch_larger_than_the_feature_buffer_is_refused_by_the_trainer_and_named_by_the_server(K, small_ds, tmp_path, capfd):
+    """VERDICT r05 next 4.  The feature buffers hold a bounded number of rows (1.2 x the largest batch of the pre-sampling epoch,
+    Server.cu:275); the reference's trainer views [nc9, F] of them unchecked (ipc_cuda_kernel.cu:200: a read past the allocation).  Here
+    (a) `ipc_service.get_next` must RAISE for a batch with more nodes than rows -- a real trainer process attached to an in-process runner
+    whose published row capacity is shrunk after the first batch -- and (b) the server must not drop rows silently: the runner names the
+    first short batch in its log and counts them all (Runner_ShortBatches)."""
+    import subprocess
+    ds = small_ds
+    B, fan = 300, [10, 5]
+    L = K.lib()
+    ns = "lgn_t_short_%d_" % os.getpid()
+    L.legion_ipc_set_namespace(ns.encode())
+    eng = make_engine(K, ds, B, fan)
+    env = L.NewIPCEnv(1)
+    L.IPCEnv_Coordinate(env, C.byref(eng.info))
+    fan_arr = np.asarray(fan, dtype=np.int32)
+    rp = K.RunnerParams()
+    rp.device_id, rp.fanout, rp.hops = 0, fan_arr.ctypes.data, len(fan)
+    rp.cache, rp.graph, rp.noder, rp.env, rp.global_batch_id, rp.in_memory = eng.cache, eng.graph, eng.noder, env, 0, 1
+    runner = L.NewGPURunner()
+    L.Runner_Initialize(runner, C.byref(rp))
+    L.Runner_InitializeFeaturesBuffer(runner, C.byref(rp))
+    L.GPUCache_SetPreSc(eng.cache, 0)
+    K.check()
+    small_rows = 100
+    log = open(str(tmp_path / "client.log"), "w+")
+    client = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ipc_client_poison.py"), str(ds.spec.F), "feature buffer holds %d rows" % small_rows],
+                              stdout=log, stderr=subprocess.STDOUT, env=dict(os.environ, LEGION_IPC_NAMESPACE=ns, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    try:
+        t0 = time.time()
+        while "ATTACHED" not in open(log.name).read():
+            assert client.poll() is None and time.time() - t0 < 240, open(log.name).read()[-3000:]
+            time.sleep(0.1)
+        L.Runner_RunOnce(runner, C.byref(rp))          # batch 0 queued
+        rp.global_batch_id = 1
+        L.Runner_RunOnce(runner, C.byref(rp))          # batch 1 queued, batch 0 handed over: complete, the trainer takes it
+        K.check()
+        while "BATCH" not in open(log.name).read():
+            assert client.poll() is None and time.time() - t0 < 240, open(log.name).read()[-3000:]
+            time.sleep(0.05)
+        assert L.Runner_ShortBatches(runner) == 0
+        # from here on the buffers "hold" 100 rows: the gather of batch 2 stops there, and batch 1 (thousands of nodes) no longer fits
+        pool = L.Runner_GetMemoryPool(runner)
+        L.GPUMemoryPool_SetFeatureRows(pool, small_rows)
+        L.IPCEnv_SetFeatureRows(env, 0, small_rows)
+        rp.global_batch_id = 2
+        L.Runner_RunOnce(runner, C.byref(rp))          # hands batch 1 over
+        K.check()
+        rc = client.wait(timeout=120)
+    except BaseException:
+        client.kill()
+        raise
+    text = open(log.name).read()
+    short = L.Runner_ShortBatches(runner)
+    L.d_stream_sync(None)
+    L.Runner_Delete(runner)
+    L.IPCEnv_Finalize(env)
+    eng.close()
+    L.legion_ipc_set_namespace(b"")
+    assert rc == 0 and "RAISED after 1 good batches" in text and "feature buffer holds %d rows" % small_rows in text, text[-3000:]
+    assert short == 1, short
+    server_said = capfd.readouterr().out
+    assert "Feature buffer too small: a batch has" in server_said and "the buffer holds %d rows" % small_rows in server_said, server_said[-1500:]
+
+
 # ---------------------------------------------------------------------------------------------------
 # cache: pre-sampling, ranking, cost model, fill-up, unified cache with Kg logical GPUs on one device
 # ---------------------------------------------------------------------------------------------------

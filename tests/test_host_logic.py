@@ -236,6 +236,32 @@ def test_client_open_refuses_a_chunk_descriptor_without_listener():
     _client_open_without_listener("lgn_t_nolisten_%d_" % os.getpid())
 
 
+def test_client_open_refuses_a_server_that_has_not_registered_its_buffers():
+    """a trainer that attaches before the server has registered its hand-off buffers (the feature buffers only exist
+    after the pre-sampling epoch, Server.cu:33,273-282) found all-zero handle slots, skipped them, and went on with null buffers -- its first
+    kernel then faulted on the GPU.  The reference fails in cudaIpcOpenMemHandle there; here the client is refused with the start order named
+    (only the device-free test mode, $LEGION_IPC_NO_DEVICE=1, may skip empty slots)."""
+    import legion1_amd.capi as K
+    L = K.lib()
+    L.legion_set_error_mode(K.ERR_RETURN)
+    ns = "lgn_t_early_%d_" % os.getpid()
+    L.legion_ipc_set_namespace(ns.encode())
+    path = "/dev/shm/" + ns + "simpleIPCshm"
+    with open(path, "wb") as f:
+        f.write(bytes(12 + 8 * 2 * 7 * 64))          # a slab whose server has registered nothing yet
+    try:
+        L.legion_clear_error()
+        client = L.legion_ipc_client_open(0)
+        msg = L.legion_last_error()
+        assert not client, "a client on null buffers must be refused"
+        assert msg and b"has not registered buffer 0 of pipe 0 of GPU 0 yet" in msg and b"System is ready for serving" in msg, msg
+        assert not os.path.exists("/dev/shm/sem." + ns + "sem_r_0_0"), "no pipe may be posted as free"
+    finally:
+        L.legion_clear_error()
+        L.legion_ipc_set_namespace(b"")
+        os.unlink(path)
+
+
 def test_shard_pitch_respects_the_cache_budget():
     """the cost model plans the feature cache in DENSE rows (capacity = budget / (F * 4), GPUCache.cu:727),
     so a shard may only take the line-aligned pitch (F = 100 -> 128 floats, +28 %) when the padded shard still fits the budget;

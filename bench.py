@@ -490,6 +490,7 @@ class LegGuard:
                             ch.kill()
                     except Exception:   # noqa: BLE001
                         pass
+                unlink_served_namespaces(c)                # a killed server never ran IPCEnv_Finalize: its slab and semaphores would stay in /dev/shm
             finally:
                 os._exit(hung_exit)
         timer = threading.Timer(timeout, fire)
@@ -684,15 +685,17 @@ def extra_leg(c, name):
         out_hs = leg_summary(c2, leg, f"uk-union-shape graph, CSR sharded over the {c.world}-GPU clique (30 % of the adjacency rows in partitioned fragments), "
                                       f"the {c2.spec.V * c2.spec.F * 4 / 1e9:.0f} GB feature table in PINNED HOST memory behind a unified HBM cache of 10 % of its rows: "
                                       "hits from the HBM shard, misses read in-kernel over PCIe (BASELINE config 4 as stated)")
-        rl = (leg["cache_info"] or {}).get("rows_last_batch") or {}
+        rl = out_hs.get("rows_last_batch") or {}
         rows = sum(rl.get(k, 0) for k in ("own_shard", "peer_shards", "backing_table"))
         g_ms = float(leg["g_ms"].mean()) if len(leg["g_ms"]) else None
         if rows and g_ms:
             miss = rl.get("backing_table", 0)
-            gbps = miss * c2.spec.F * 4 / (g_ms * 1e-3) / 1e9
+            avg_rows = leg["job_nodes"] / (a.steps * c.world)           # rows per timed batch; the miss share is the last batch's
+            gbps = avg_rows * (miss / rows) * c2.spec.F * 4 / (g_ms * 1e-3) / 1e9
             out_hs["host_spill"] = {"rows_last_batch": rows, "miss_rows_last_batch": miss, "hit_rate": round(1.0 - miss / rows, 4),
                                     "pcie_read_GBps": round(gbps, 2), "pcie_peak_GBps": PCIE_PEAK_GBPS, "pcie_frac_of_peak": round(gbps / PCIE_PEAK_GBPS, 4),
-                                    "how": "miss rows of the last batch x 4F bytes / the gather's average HIP-event time (lookups included)"}
+                                    "how": "rows per timed batch x the last batch's miss share x 4F bytes / the gather's average HIP-event time (lookups and the hits' "
+                                           "HBM reads included); the peak is PCIe Gen5 x16 one way, nominal -- the batch is bound by the host link, not by HBM"}
         out_hs["table_generate_and_pin_s"] = round(pin_s, 1)
         return out_hs
     # uk_union / partitioned_csr: legion_server.py:23-37 shape, 2-hop GCN fan-out; the hottest 30 % of the adjacency rows as partitioned CSR
@@ -821,6 +824,16 @@ def own_audit_counts(L):
             "first_violations": [L.legion_audit_message(i).decode()[:300] for i in range(min(3, L.legion_audit_message_count()))]}
 
 
+def unlink_served_namespaces(c, only=None):
+    """A `legion` server that was KILLED (a failed or hung served leg) leaves its shm slab, the extension object and 2 x depth named semaphores
+    per GPU in /dev/shm -- one set per failed leg per run.  Remove them: every namespace a served leg of this run used, or `only`."""
+    for ns in ([only] if only else list(getattr(c, "served_namespaces", []))):
+        try:
+            c.L.legion_ipc_unlink_namespace(ns.encode(), 8)
+        except Exception:   # noqa: BLE001 -- cleaning up must never cost the line
+            pass
+
+
 def served_deadline(c):
     """Seconds a served leg gives ITS child processes before it stops them and raises: well inside what the watchdog granted the leg, so that a
     server or consumer that never comes back is a leg that FAILED (reported, exit code 0, the ranks stay in step) and not a leg that hung (exit code 3)."""
@@ -882,6 +895,7 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0, consumer="nul
     with open(meta, "w") as f:
         f.write("%s %d %d 0 %d %d %d %d %d %d %d" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, int(cache_bytes), epochs, 2 if lp else 0))
     env = dict(os.environ, LEGION_IPC_NAMESPACE="bs%d_%d_" % (os.getpid(), len(c.children)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    c.served_namespaces = getattr(c, "served_namespaces", []) + [env["LEGION_IPC_NAMESPACE"]]
     if cache_bytes > 0:
         env["LEGION_SYNTH_CACHE"] = "1"      # build the hotness cache on top of the generated tables: cost model, FillUp, cached gather / partitioned sampler
     env.pop("LEGION_LOG", None)          # the server's log is its stdout (a file here), as with the reference
@@ -916,10 +930,14 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0, consumer="nul
             raise RuntimeError("the server failed (%d): %s" % (srv.returncode, open(log_path, errors="ignore").read()[-600:]))
         log_text = open(log_path, errors="ignore").read()
     finally:
+        killed = False
         for p in (cons, srv):
             if p is not None and p.poll() is None:
                 p.kill()
                 p.wait()
+                killed = True
+        if killed or (srv is not None and srv.returncode != 0):
+            unlink_served_namespaces(c, env["LEGION_IPC_NAMESPACE"])
         shutil.rmtree(tmp, ignore_errors=True)
     got = json.loads(out.strip().splitlines()[-1])
     ts, vs, es = got["steps"]
@@ -948,7 +966,7 @@ def served_leg(c, workload, fan, ref_leg, lp=False, cache_bytes=0, consumer="nul
     train_t = float(sum(t[e * (ts + vs) + ts - 1] - t[max(e * (ts + vs) - 1, 0)] for e in range(epochs)))
     if reading is not None:
         rb = np.asarray(got["read_bytes"], np.int64)[is_train]
-        reading.update(read_GB_per_batch=round(float(rb.mean()) / 1e9, 4), consumer_read_GBps=round(float(rb.mean()) / (ms * 1e-3) / 1e9, 1),
+        reading.update(read_GB_per_batch=round(float(rb.mean()) / 1e9, 4), consumer_read_GB_per_s_of_wall_clock=round(float(rb.mean()) / (ms * 1e-3) / 1e9, 1),
                        reads="every served feature row ([nc9, F] view) and both COO arrays, summed word by word on the consumer's own stream before the pipe "
                              "goes back (legion_sum_words): the memory traffic of legion_graphsage.py:72-89 without the model")
     return {"what": "the `legion` server binary (fresh child process; dataset source %s: tables generated in its HBM; pre-sampling epoch; default "
@@ -1011,6 +1029,7 @@ def served_all_leg(c):
     with open(meta, "w") as f:
         f.write("%s %d %d 0 %d %d %d %d 0 %d 0" % (src, B, spec.V, spec.F, spec.n_train, n_eval, n_eval, epochs))
     env = dict(os.environ, LEGION_IPC_NAMESPACE="ba%d_%d_" % (os.getpid(), len(c.children)), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    c.served_namespaces = getattr(c, "served_namespaces", []) + [env["LEGION_IPC_NAMESPACE"]]
     for k in ("LEGION_LOG", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LEGION_IPC_DEVICE"):
         env.pop(k, None)
     log_path = os.path.join(tmp, "server.log")
@@ -1047,10 +1066,14 @@ def served_all_leg(c):
             raise RuntimeError("the server failed (%d): %s" % (srv.returncode, open(log_path, errors="ignore").read()[-600:]))
         log_text = open(log_path, errors="ignore").read()
     finally:
+        killed = False
         for p in cons + [srv]:
             if p is not None and p.poll() is None:
                 p.kill()
                 p.wait()
+                killed = True
+        if killed or (srv is not None and srv.returncode != 0):
+            unlink_served_namespaces(c, env["LEGION_IPC_NAMESPACE"])
         shutil.rmtree(tmp, ignore_errors=True)
     ts, vs, es = outs[0]["steps"]
     per_gpu_ms, per_gpu_edges, per_gpu_nodes, n_windows = [], [], [], []

@@ -171,6 +171,40 @@ struct SampleArgs {
     int32_t prefilter_from_op; // first op_id whose claims are preceded by the pre-filter load (4: hop 2; hop 1 never)
 };
 
+// One slot's probe + claim on the position table.  Returns the slot's state: -1 = claim pending / won, >= 0 = the neighbour's known final
+// position, <= -2 = lost to slot -2 - x.
+__device__ inline int32_t claim_slot(const SampleArgs& a, uint32_t epoch, int32_t dst, int32_t idx)
+{
+    // claim: lowest idx wins.  Entries of older batches have a larger epoch field, i.e. compare
+    // greater: unseen.  A stale (larger) pre-filter read only costs a redundant atomic.
+    const pos_t prov0 = pos_entry(epoch, kProvisional);
+    const pos_t mine = prov0 | (pos_t)(uint32_t)idx;
+    // (plain loads: a non-temporal hint on this pre-filter load costs +11 % of k_sample, on the neighbour load
+    // nothing, profiles/r02_sampler_experiments.md)
+    // hop 1: nearly every neighbour is new, so the pre-filter load would only add a dependent round trip in front
+    // of the claim -- go straight to the atomic (it returns the exact entry either way)
+    pos_t cur = (a.op_id < a.prefilter_from_op) ? ~(pos_t)0 : a.pos_map[dst];
+    if (cur > mine) {
+        const pos_t old = atomicMin(a.pos_map + dst, mine);
+        if (old > mine) {
+            // the table holds this slot's claim now.  If it replaced a claim of this hop (a larger
+            // slot that got there first), that slot has lost for good: tell it who beat it.  Its own
+            // thread left aux at -1 (pending) and never writes it again, so this is the only store.
+            if ((uint32_t)(old >> kPosShift) == epoch) a.aux[(uint32_t)old & kPosValueMask] = -2 - idx;
+            cur = mine;
+        } else {
+            cur = old; // a smaller entry arrived between the load and the atomic: exact value
+        }
+    }
+    // final positions are only written by earlier launches: if we see one it is exact
+    if (cur < prov0) return (int32_t)((uint32_t)cur & kPosValueMask);
+    // a smaller claim of this hop is in the table: this slot has lost for good (claims only
+    // decrease).  Point at that slot; if it loses later too, its own aux points further, and
+    // k_write follows the chain to the winner.
+    if (cur < mine) return -2 - (int32_t)((uint32_t)cur & kPosValueMask);
+    return -1;
+}
+
 template <bool PRESC, bool PARTITIONED>
 __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
 {
@@ -258,37 +292,8 @@ __global__ __launch_bounds__(kBlock) void k_sample(SampleArgs a)
             }
             if (dst >= 0) {
                 if (PRESC) atomicAdd(a.edge_access_time + s_src[r], 1ull); // Kernels.cu:525
-                if (dup) {
-                    known = -2 - (idx - dup);
-                } else {
-                    // claim: lowest idx wins.  Entries of older batches have a larger epoch field, i.e. compare
-                    // greater: unseen.  A stale (larger) pre-filter read only costs a redundant atomic.
-                    const pos_t prov0 = pos_entry(epoch, kProvisional);
-                    const pos_t mine = prov0 | (pos_t)(uint32_t)idx;
-                    // (plain loads: a non-temporal hint on this pre-filter load costs +11 % of k_sample, on the neighbour load
-                    // nothing, profiles/r02_sampler_experiments.md)
-                    // hop 1: nearly every neighbour is new, so the pre-filter load would only add a dependent round trip in front
-                    // of the claim -- go straight to the atomic (it returns the exact entry either way)
-                    pos_t cur = (a.op_id < a.prefilter_from_op) ? ~(pos_t)0 : a.pos_map[dst];
-                    if (cur > mine) {
-                        const pos_t old = atomicMin(a.pos_map + dst, mine);
-                        if (old > mine) {
-                            // the table holds this slot's claim now.  If it replaced a claim of this hop (a larger
-                            // slot that got there first), that slot has lost for good: tell it who beat it.  Its own
-                            // thread left aux at -1 (pending) and never writes it again, so this is the only store.
-                            if ((uint32_t)(old >> kPosShift) == epoch) a.aux[(uint32_t)old & kPosValueMask] = -2 - idx;
-                            cur = mine;
-                        } else {
-                            cur = old; // a smaller entry arrived between the load and the atomic: exact value
-                        }
-                    }
-                    // final positions are only written by earlier launches: if we see one it is exact
-                    if (cur < prov0) known = (int32_t)((uint32_t)cur & kPosValueMask);
-                    // a smaller claim of this hop is in the table: this slot has lost for good (claims only
-                    // decrease).  Point at that slot; if it loses later too, its own aux points further, and
-                    // k_write follows the chain to the winner.
-                    else if (cur < mine) known = -2 - (int32_t)((uint32_t)cur & kPosValueMask);
-                }
+                if (dup) known = -2 - (idx - dup);
+                else known = claim_slot(a, epoch, dst, idx);
                 cnt++;
             }
             if (idx < tile_end) {

@@ -110,7 +110,7 @@ def test_one_gpu_line_has_every_single_gpu_baseline_path():
     # stream, before the pipe goes back -- with one batch's sums checked (features against the generator's closed form of the rows the batch names);
     # the null consumer (the hand-off alone) sits beside it
     rc = sv["reading_consumer"]
-    assert sv["consumer"] == "reading" and rc["read_GB_per_batch"] > 0 and rc["consumer_read_GBps"] > 0
+    assert sv["consumer"] == "reading" and rc["read_GB_per_batch"] > 0 and rc["consumer_read_GB_per_s_of_wall_clock"] > 0
     ck = rc["checksum"]
     assert ck["features_equal_the_generators_rows"] is True and ck["coo_src_equal_host_copy"] is True and ck["coo_dst_equal_host_copy"] is True and ck["rows"] > 0, ck
     nul = sv["null_consumer"]

@@ -51,6 +51,26 @@ def assert_batch_equal(ref, got, keys=BATCH_KEYS):
             raise AssertionError(f"{k}: {len(bad)} mismatches, first at {bad[:5]}: {a.reshape(-1)[bad[:5]]} vs {b.reshape(-1)[bad[:5]]}")
 
 
+AUDIT_TOTALS = {"tests": 0, "checks": 0, "unattributed": 0, "peer_launches": 0, "servers": []}      # evidence for the terminal summary
+
+
+def note_server_audit(counts):
+    """A `legion` server (child process) left this audit summary in its log (tests/test_gpu_ipc.py, tests/test_gpu_bench_legs.py)."""
+    AUDIT_TOTALS["servers"].append(counts)
+
+
+def pytest_terminal_summary(terminalreporter):
+    t = AUDIT_TOTALS
+    if t["tests"] == 0 and not t["servers"]:
+        return
+    terminalreporter.write_line("device audit (LEGION_DEVICE_AUDIT=1): %d GPU tests, %d checks in this process, 0 violations (a violation fails its test), "
+                                "%d unattributed, %d launches with a peer's table" % (t["tests"], t["checks"], t["unattributed"], t["peer_launches"]))
+    if t["servers"]:
+        terminalreporter.write_line("device audit of %d `legion` server processes: %d checks, %d violations, %d unattributed, %d launches with a peer's table" % (
+            len(t["servers"]), sum(s["checks"] for s in t["servers"]), sum(s["violations"] for s in t["servers"]),
+            sum(s["unattributed"] for s in t["servers"]), sum(s["peer_launches"] for s in t["servers"])))
+
+
 @pytest.fixture(autouse=True)
 def _no_device_audit_violation(request):
     """After every test: the library of THIS process must not have recorded a wrong-device violation (tests that provoke one
@@ -61,6 +81,7 @@ def _no_device_audit_violation(request):
     capi = sys.modules.get("legion1_amd.capi")
     if capi is not None and capi._lib is not None and capi._lib.legion_audit_enabled():
         capi._lib.SetGPUDevice(0)
+        capi._lib.legion_audit_reset()          # per-test counts (summed below for the terminal summary)
     yield
     capi = sys.modules.get("legion1_amd.capi")
     if capi is None or capi._lib is None or not capi._lib.legion_audit_enabled():
@@ -68,6 +89,10 @@ def _no_device_audit_violation(request):
     import ctypes
     c = (ctypes.c_int64 * 4)()
     capi._lib.legion_audit_counts(c)
+    AUDIT_TOTALS["tests"] += 1
+    AUDIT_TOTALS["checks"] += c[0]
+    AUDIT_TOTALS["unattributed"] += c[2]
+    AUDIT_TOTALS["peer_launches"] += c[3]
     if c[1]:
         msgs = [capi._lib.legion_audit_message(i).decode() for i in range(min(5, capi._lib.legion_audit_message_count()))]
         capi._lib.legion_audit_reset()

@@ -57,6 +57,8 @@ def test_two_rank_line_has_every_leg():
         da, sda = line["device_audit"], sa["server_device_audit"]
         assert da["violations"] == 0 and da["checks"] > 1000, da
         assert sda["violations"] == 0 and sda["unattributed"] == 0 and sda["checks"] > 1000, sda
+        from conftest import note_server_audit
+        note_server_audit(sda)
 
 
 def test_a_failed_leg_is_named_and_the_other_legs_survive():
@@ -70,7 +72,7 @@ def test_a_failed_leg_is_named_and_the_other_legs_survive():
 
 
 def test_a_hung_leg_ends_every_rank_with_exit_code_3_and_the_headline_is_printed():
-    r, line = _bench({"LEGION_BENCH_INJECT_HANG": "unified_cache:1"}, "--unified-timeout", "25")
+    r, line = _bench({"LEGION_BENCH_INJECT_HANG": "unified_cache:1"}, "--unified-timeout", "12")
     assert r.returncode == 3, (r.returncode, r.stderr[-3000:])
     assert line is not None and line["value"] > 0 and line["n_gpus"] == 2            # the headline survived
     assert line["legs_failed"][0]["leg"] == "unified_cache" and line["legs_failed"][0]["hung"] is True

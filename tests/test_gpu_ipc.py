@@ -28,6 +28,8 @@ def _audit_clean(log_text, gpus=1):
     assert m, log_text[-1500:]
     checks, bad, unattributed, peer = (int(x) for x in m.groups())
     assert checks > 100 * gpus and bad == 0 and unattributed == 0, (m.group(0), log_text[-1500:])
+    from conftest import note_server_audit
+    note_server_audit(dict(checks=checks, violations=bad, unattributed=unattributed, peer_launches=peer))
     return dict(checks=checks, violations=bad, unattributed=unattributed, peer_launches=peer)
 
 
@@ -73,6 +75,7 @@ def test_server_binary_to_ipc_service(tmp_path, synth, oracle, fan, budget_frac,
         assert client.returncode == 0, client.stdout[-2000:] + client.stderr[-3000:]
         server.wait(timeout=60)
         assert server.returncode == 0, open(log).read()[-3000:]
+        _audit_clean(open(log).read())
     finally:
         if server.poll() is None:
             server.kill()
@@ -142,6 +145,7 @@ def test_server_synth_dataset_source(tmp_path, synth, oracle, workload, scale, f
             assert c.returncode == 0, stdout[-3000:]
         server.wait(timeout=60)
         assert server.returncode == 0, open(log).read()[-3000:]
+        _audit_clean(open(log).read())
     finally:
         for _, c in clients:
             if c.poll() is None:
@@ -197,6 +201,7 @@ def test_server_synth_link_prediction_lists(tmp_path, synth, oracle, G):
             assert c.returncode == 0, stdout[-3000:]
         server.wait(timeout=60)
         assert server.returncode == 0, open(log).read()[-3000:]
+        _audit_clean(open(log).read())
     finally:
         for _, c in clients:
             if c.poll() is None:
@@ -296,6 +301,7 @@ def test_synchronize_with_queued_trainer_work(tmp_path, synth, oracle):
         assert client.returncode == 0, client.stdout[-2000:] + client.stderr[-3000:]
         server.wait(timeout=60)
         assert server.returncode == 0, open(log).read()[-3000:]
+        _audit_clean(open(log).read())
     finally:
         if server.poll() is None:
             server.kill()
@@ -411,6 +417,7 @@ def test_torch_trainer_learns_from_served_batches(tmp_path, synth, model):
         assert tr.returncode == 0, tr.stdout[-2000:] + tr.stderr[-3000:]
         server.wait(timeout=60)
         assert server.returncode == 0, open(log).read()[-3000:]
+        _audit_clean(open(log).read())
     finally:
         if server.poll() is None:
             server.kill()
@@ -454,6 +461,7 @@ def test_torch_link_prediction_trainer_on_triple_seeds(tmp_path, synth):
         assert tr.returncode == 0, tr.stdout[-2000:] + tr.stderr[-3000:]
         server.wait(timeout=60)
         assert server.returncode == 0, open(log).read()[-3000:]
+        _audit_clean(open(log).read())
     finally:
         if server.poll() is None:
             server.kill()

@@ -687,15 +687,17 @@ def extra_leg(c, name):
                                       "hits from the HBM shard, misses read in-kernel over PCIe (BASELINE config 4 as stated)")
         rl = out_hs.get("rows_last_batch") or {}
         rows = sum(rl.get(k, 0) for k in ("own_shard", "peer_shards", "backing_table"))
-        g_ms = float(leg["g_ms"].mean()) if len(leg["g_ms"]) else None
-        if rows and g_ms:
+        g = np.asarray(leg["g_ms"], np.float64)
+        # the gather launches of the LAST timed batch of every window: the batch whose rows were classified (same rows, same time)
+        g_last = float(g.reshape(-1, a.steps)[:, -1].mean()) if len(g) and len(g) % a.steps == 0 else (float(g.mean()) if len(g) else None)
+        if rows and g_last:
             miss = rl.get("backing_table", 0)
-            avg_rows = leg["job_nodes"] / (a.steps * c.world)           # rows per timed batch; the miss share is the last batch's
-            gbps = avg_rows * (miss / rows) * c2.spec.F * 4 / (g_ms * 1e-3) / 1e9
+            gbps = miss * c2.spec.F * 4 / (g_last * 1e-3) / 1e9
             out_hs["host_spill"] = {"rows_last_batch": rows, "miss_rows_last_batch": miss, "hit_rate": round(1.0 - miss / rows, 4),
+                                    "gather_ms_last_batch": round(g_last, 3),
                                     "pcie_read_GBps": round(gbps, 2), "pcie_peak_GBps": PCIE_PEAK_GBPS, "pcie_frac_of_peak": round(gbps / PCIE_PEAK_GBPS, 4),
-                                    "how": "rows per timed batch x the last batch's miss share x 4F bytes / the gather's average HIP-event time (lookups and the hits' "
-                                           "HBM reads included); the peak is PCIe Gen5 x16 one way, nominal -- the batch is bound by the host link, not by HBM"}
+                                    "how": "miss rows of the last timed batch x 4F bytes / the HIP-event time of that batch's gather launches (lookups and the hits' HBM "
+                                           "reads included); the peak is PCIe Gen5 x16 one way, nominal -- the batch is bound by the host link, not by HBM"}
         out_hs["table_generate_and_pin_s"] = round(pin_s, 1)
         return out_hs
     # uk_union / partitioned_csr: legion_server.py:23-37 shape, 2-hop GCN fan-out; the hottest 30 % of the adjacency rows as partitioned CSR
